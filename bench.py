@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X (BASELINE.json).
+
+metric : aligned audio hours/sec (CTC DP frames/s), whole job over all N GPUs
+workload: BASELINE.json configs[2] -- synthetic DP-only, 512 segments x 3000 frames x vocab 32
+          (C = 640 label columns, 22 utterances/segment), per GPU (weak scaling).
+step   : one pass of the hot path (trellis fill + backtrack + utterance scoring) over that
+          batch, inputs resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+INDEX_DURATION = 320.4769 / 16000  # s per frame (wav2vec2: 215040 samples -> 671 frames)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--segments", type=int, default=512, help="segments per GPU")
+    ap.add_argument("--frames", type=int, default=3000)
+    ap.add_argument("--vocab", type=int, default=32)
+    ap.add_argument("--utts", type=int, default=22)
+    ap.add_argument("--utt-len", type=int, default=28)
+    ap.add_argument("--cols-per-lane", type=int, default=int(os.environ.get("CTCFA_K", "0")))
+    ap.add_argument("--cpu-sample", type=int, default=256, help="segments timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of segment boundaries")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import __graft_entry__ as ge
+
+    pkg = ge.build()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- synthetic workload (SURVEY §8(d) recipe), this rank's shard ----------------------
+    syn = pkg.synthetic
+    B, T, V, U, n = args.segments, args.frames, args.vocab, args.utts, args.utt_len
+    lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, seed0=rank * B)
+    C = gt.shape[1]
+    cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
+    eng = pkg._native.Engine(local_rank)
+    plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane)
+    info = plan.info
+
+    d_lpz = torch.from_numpy(lpz.reshape(-1)).to(dev)
+    d_lab = torch.from_numpy(gt.astype(np.int32).reshape(-1)).to(dev)
+    d_ub = torch.from_numpy(ub.astype(np.int32).reshape(-1)).to(dev)
+    d_fol = torch.empty(B * C, dtype=torch.int32, device=dev)
+    d_cp = torch.empty(B * T, dtype=torch.float32, device=dev)
+    d_seg = torch.empty(3, B * U, dtype=torch.float64, device=dev)
+    d_te = torch.empty(B, dtype=torch.int32, device=dev)
+    d_status = torch.empty(B, dtype=torch.int32, device=dev)
+    gathered = torch.empty(world, 3, B * U, dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+
+    def step():
+        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), d_fol.data_ptr(),
+                        d_cp.data_ptr(), None, d_seg[0].data_ptr(), d_seg[1].data_ptr(),
+                        d_seg[2].data_ptr(), d_te.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+        if world > 1 and not args.no_gather:
+            # the path's only exchange: gather the final segment boundaries (role of
+            # merge_aligned_files.py:17-25), on a side stream so it overlaps the next step
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered.view(-1), d_seg.view(-1))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    plan.set_timing(min(args.steps, 1024))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if side is not None:
+        stream.wait_stream(side)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    n_timed = min(args.steps, 1024)
+    fill_ms, bt_ms = plan.get_timings(n_timed)
+
+    # ---- parity gate on the timed inputs (a sample; the full sweep is tests/ -m gpu) -------
+    status = d_status.cpu().numpy()
+    assert (status == 0).all(), "non-OK status in the benchmark batch"
+    parity = None
+    if rank == 0:
+        from oracle import oracle_c
+        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
+        fol = d_fol.cpu().numpy().reshape(B, C)
+        seg = d_seg.cpu().numpy().reshape(3, B, U)
+        cp = d_cp.cpu().numpy().reshape(B, T)
+        for b in (0, B // 2, B - 1):
+            o = oracle_c.get_segments(lpz[b], gt[b], ub[b], ocfg)
+            assert np.array_equal(fol[b], o["frame_of_label"]), f"segment {b}: frame indices differ from oracle"
+            assert np.array_equal(cp[b].astype(np.float64), o["char_probs"])
+            assert np.allclose(seg[2][b], o["seg_score"], rtol=0, atol=1e-4)
+        parity = "3 segments == oracle (frames bit-exact, scores<=1e-4)"
+
+    # ---- CPU baseline: the oracle (kind "port") on a bounded sample, rank 0, N == 1 only ---
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import oracle_c
+        ns = min(args.cpu_sample, B)
+        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
+        sec, st, _ = oracle_c.time_uniform_batch(lpz[:ns], gt[:ns], ub[:ns], ocfg)
+        fps = ns * T / sec
+        cpu = {"value": fps * INDEX_DURATION / 3600.0, "unit": "audio-hours/s", "frames_per_s": fps,
+               "cores": 1, "kind": "port",
+               "sample": f"{ns} of the {B} benchmark segments ({T} frames x {C} columns), "
+                         f"oracle/ctc_segmentation_oracle.c single thread, {sec:.1f} s",
+               "host_cores": os.cpu_count()}
+
+    if rank == 0:
+        frames_total = world * B * T * args.steps
+        fps = frames_total / dt
+        value = fps * INDEX_DURATION / 3600.0
+        fill_avg_s = float(np.mean(fill_ms)) * 1e-3
+        alg = info["algorithmic_bytes"]
+        achieved = alg / fill_avg_s / 1e9
+        out = {
+            "metric": "aligned audio hours/sec (CTC DP frames/s)",
+            "value": value, "unit": "audio-hours/s", "frames_per_s": fps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: synthetic DP-only, %d segments x %d frames x "
+                                   "vocab %d per GPU, C=%d label columns, %d utterances/segment"
+                                   % (B, T, V, C, U),
+                       "segments_per_gpu": B, "frames": T, "vocab": V, "label_columns": C,
+                       "cols_per_lane": info["cols_per_lane"], "waves_per_segment": info["waves_per_seg"],
+                       "parallelism": f"segment-sharded x{world}", "parity": parity},
+            "roofline": {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms_avg": float(np.mean(fill_ms)), "kernel_ms_min": float(np.min(fill_ms)),
+                         "backtrack_kernel_ms_avg": float(np.mean(bt_ms))},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * ctcfa.h -- C ABI of the MI355X (gfx950) CTC forced-alignment engine.
+ *
+ * This is the drop-in boundary for the one hot path of
+ * ferugit/iterative-pseudo-forced-alignment-ctc: the per-window CTC-segmentation
+ * trellis DP + backtrack + utterance scoring that the reference reaches through
+ *     aligner.get_segments(task)      src/iterative_utterance_alignment.py:216
+ *                                     src/word_level_alignment.py:100
+ *                                     src/search_on_speech.py:85
+ * i.e. SpeechBrain's CTCSegmentation.get_segments -> ctc_segmentation.ctc_segmentation
+ * (-> Cython cython_fill_table) -> determine_utterance_segments
+ * (ctc-segmentation==1.7.1, speechbrain==0.5.11; requirements.txt:13,87).
+ * Each entry point below names the reference-side interface it replaces.
+ *
+ * Plain C: opaque handles, raw pointers, sizes.  No torch / numpy types.
+ * The library has NO CPU fallback: every compute entry needs a HIP device and
+ * returns CTCFA_ERR_HIP otherwise.
+ *
+ * Batch geometry ("plan"): B independent segments, ragged.
+ *   segment b:  lpz      fp32 [T_b, V]   at  lpz     + lpz_off[b]      (elements)
+ *               labels   i32  [C_b]      at  labels  + lab_off[b]      (ground_truth_mat[:,0]; [0] == -1)
+ *               utt_begin i32 [U_b + 1]  at  utt_begin + utt_off[b] + b
+ *   outputs:    frame_of_label i32 [C_b] at  + lab_off[b]   (timings[c] / index_duration)
+ *               char_prob      f32 [T_b] at  + frm_off[b]   (frm_off = prefix sum of T)
+ *               state          i32 [T_b] at  + frm_off[b]   (label id | -1 "ε" | -2 untouched)
+ *               seg_start/end/score f64 [U_b] at + utt_off[b]
+ *               t_end, status  i32 [B]
+ */
+#ifndef CTCFA_H
+#define CTCFA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTCFA_VERSION 100 /* 0.1.0 */
+
+/* return codes of the API calls */
+#define CTCFA_OK 0
+#define CTCFA_ERR_INVALID 1     /* bad argument / API misuse                       */
+#define CTCFA_ERR_HIP 2         /* HIP runtime error or no device                  */
+#define CTCFA_ERR_UNSUPPORTED 3 /* valid request outside what the kernels cover    */
+#define CTCFA_ERR_NOMEM 4
+
+/* per-segment status[b] (what the reference would have raised) */
+#define CTCFA_ST_OK 0
+#define CTCFA_ST_AUDIO_SHORTER_THAN_TEXT 1 /* AssertionError("Audio is shorter than text!"),
+                                              caught at iterative_utterance_alignment.py:390 */
+#define CTCFA_ST_BACKTRACK_FAILED 2        /* IndexError re-raised by ctc_segmentation()      */
+#define CTCFA_ST_WINDOWED_UNSUPPORTED 3    /* T > min_window_size: DP-window regime */
+
+/* flags (CtcSegmentationParameters.flags + the backtrack switch) */
+#define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; not yet supported */
+#define CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO 2u /* default of the package         */
+#define CTCFA_FLAG_BACKTRACK_FROM_MAX_T 4u
+
+/* CtcSegmentationParameters fields the DP reads (test_ctc_segmentation.py:20-38 names them). */
+typedef struct ctcfa_params {
+    int32_t blank;                 /* config.blank, default 0                    */
+    uint32_t flags;                /* CTCFA_FLAG_*; the production scripts use 2 */
+    int32_t min_window_size;       /* 8000                                       */
+    int32_t max_window_size;       /* 100000                                     */
+    int32_t score_min_mean_over_L; /* scoring_length=30 (iterative_utterance_alignment.py:418) */
+    int32_t reserved;
+    double index_duration;         /* samples_to_frames_ratio / fs ("fixed" time stamps) */
+} ctcfa_params;
+
+typedef struct ctcfa_engine ctcfa_engine; /* one per (process, device); owns a HIP stream */
+typedef struct ctcfa_plan ctcfa_plan;     /* batch geometry + device workspace            */
+
+/* launch-shape report (for DESIGN/bench bookkeeping) */
+typedef struct ctcfa_plan_info {
+    int32_t batch;
+    int32_t cols_per_lane;   /* K                                   */
+    int32_t waves_per_seg;   /* W  (workgroup = 64*W threads)       */
+    int32_t vocab_pitch;     /* LDS row pitch in entries            */
+    int32_t lds_bytes;       /* dynamic LDS of the fill kernel      */
+    int32_t n_blocks_max;    /* 32-row blocks of the longest segment */
+    int64_t workspace_bytes; /* decision bits + last-column scores  */
+    int64_t algorithmic_bytes; /* sum_b 4TV + TC/8 + 4T + 8C + 4T */
+    int64_t total_frames;
+} ctcfa_plan_info;
+
+int ctcfa_version(void);
+const char* ctcfa_status_string(int status);
+
+/* Engine.  device >= 0 selects the HIP device. */
+int ctcfa_engine_create(ctcfa_engine** out, int device);
+void ctcfa_engine_destroy(ctcfa_engine* eng);
+const char* ctcfa_last_error(const ctcfa_engine* eng);
+void ctcfa_default_params(ctcfa_params* p); /* CtcSegmentationParameters defaults, flags = 2 */
+
+/*
+ * Plan = the shapes of one batch.  Host arrays: T[B], C[B], U[B] (U may be NULL:
+ * no utterance scoring).  Replaces the per-call shape handling of
+ * ctc_segmentation(): the `len(ground_truth) > lpz.shape[0]` assertion and the
+ * `min(window_size, lpz.shape[0])` window decision become per-segment status.
+ * force_cols_per_lane: 0 = heuristic, else K in {1,2,3,4,5,6,8,10,12,16}.
+ */
+int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params,
+                      int32_t batch, int32_t vocab, const int32_t* T, const int32_t* C,
+                      const int32_t* U, int32_t force_cols_per_lane);
+void ctcfa_plan_destroy(ctcfa_plan* plan);
+int ctcfa_plan_get_info(const ctcfa_plan* plan, ctcfa_plan_info* info);
+
+/*
+ * Run a plan on DEVICE-resident buffers (layout in the header comment).
+ * Replaces, batched:  cython_fill_table + the backtrack loop of ctc_segmentation()
+ * + determine_utterance_segments().  `stream` is a hipStream_t (NULL = the
+ * engine's own stream); the call only enqueues work.
+ * d_state, d_utt_begin, d_seg_* may be NULL (skipped).
+ */
+int ctcfa_plan_run_device(ctcfa_plan* plan, const float* d_lpz, const int32_t* d_labels,
+                          const int32_t* d_utt_begin, int32_t* d_frame_of_label,
+                          float* d_char_prob, int32_t* d_state, double* d_seg_start,
+                          double* d_seg_end, double* d_seg_score, int32_t* d_t_end,
+                          int32_t* d_status, void* stream);
+
+/* Kernel timing with HIP events recorded on the stream the kernels run on.
+ * set_timing(slots): keep the events of the last `slots` runs (0 = off, the default).
+ * get_timings(n, ...): durations [ms] of the last n runs, oldest first; synchronises
+ * on those runs' end events.  fill_ms / backtrack_ms: float[n], either may be NULL. */
+int ctcfa_plan_set_timing(ctcfa_plan* plan, int slots);
+int ctcfa_plan_get_timings(ctcfa_plan* plan, int n, float* fill_ms, float* backtrack_ms);
+
+/*
+ * Host-buffer convenience entry: same computation with HOST pointers; uploads,
+ * runs, downloads and synchronises.  This is the call the reference-side binding
+ * uses in place of `ctc_segmentation(config, lpz, ground_truth_mat)` +
+ * `determine_utterance_segments(...)`.
+ */
+int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                      const int32_t* T, const int32_t* C, const int32_t* U, const float* lpz,
+                      const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label,
+                      float* char_prob, int32_t* state, double* seg_start, double* seg_end,
+                      double* seg_score, int32_t* t_end, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTCFA_H */

@@ -1,0 +1,251 @@
+"""ctypes binding of the C ABI in ``include/ctcfa.h`` (``csrc/libctcfa_hip.so``).
+
+The shared library is the product's only compute path for the CTC-segmentation DP
+(the part the reference reaches through ``aligner.get_segments(task)``,
+/root/reference/src/iterative_utterance_alignment.py:216).  There is no CPU
+fallback: if the library is missing or no HIP device is present every call here
+raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libctcfa_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, 1, 2, 3, 4
+ST_OK, ST_AUDIO_SHORTER_THAN_TEXT, ST_BACKTRACK_FAILED, ST_WINDOWED_UNSUPPORTED = 0, 1, 2, 3
+FLAG_BLANK_TRANSITION_COST_ZERO, FLAG_PREAMBLE_TRANSITION_COST_ZERO, FLAG_BACKTRACK_FROM_MAX_T = 1, 2, 4
+
+# every symbol include/ctcfa.h declares
+EXPORTS = (
+    "ctcfa_version", "ctcfa_status_string", "ctcfa_engine_create", "ctcfa_engine_destroy",
+    "ctcfa_last_error", "ctcfa_default_params", "ctcfa_plan_create", "ctcfa_plan_destroy",
+    "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_get_timings",
+    "ctcfa_plan_set_timing", "ctcfa_align_batch",
+)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    _fields_ = [
+        ("blank", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("min_window_size", ctypes.c_int32),
+        ("max_window_size", ctypes.c_int32),
+        ("score_min_mean_over_L", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("index_duration", ctypes.c_double),
+    ]
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [
+        ("batch", ctypes.c_int32),
+        ("cols_per_lane", ctypes.c_int32),
+        ("waves_per_seg", ctypes.c_int32),
+        ("vocab_pitch", ctypes.c_int32),
+        ("lds_bytes", ctypes.c_int32),
+        ("n_blocks_max", ctypes.c_int32),
+        ("workspace_bytes", ctypes.c_int64),
+        ("algorithmic_bytes", ctypes.c_int64),
+        ("total_frames", ctypes.c_int64),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU fallback. "
+            "Run __graft_entry__.build().")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    lib.ctcfa_version.restype = ctypes.c_int
+    lib.ctcfa_status_string.restype = ctypes.c_char_p
+    lib.ctcfa_status_string.argtypes = [ctypes.c_int]
+    lib.ctcfa_last_error.restype = ctypes.c_char_p
+    lib.ctcfa_last_error.argtypes = [vp]
+    lib.ctcfa_engine_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.ctcfa_engine_destroy.argtypes = [vp]
+    lib.ctcfa_engine_destroy.restype = None
+    lib.ctcfa_default_params.argtypes = [ctypes.POINTER(Params)]
+    lib.ctcfa_default_params.restype = None
+    lib.ctcfa_plan_create.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(Params), ctypes.c_int32,
+                                      ctypes.c_int32, i32p, i32p, i32p, ctypes.c_int32]
+    lib.ctcfa_plan_destroy.argtypes = [vp]
+    lib.ctcfa_plan_destroy.restype = None
+    lib.ctcfa_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
+    lib.ctcfa_plan_run_device.argtypes = [vp] + [vp] * 12
+    lib.ctcfa_plan_get_timings.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_float)]
+    lib.ctcfa_plan_set_timing.argtypes = [vp, ctypes.c_int]
+    lib.ctcfa_align_batch.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
+                                      i32p, i32p, i32p] + [vp] * 11
+    _lib = lib
+    return lib
+
+
+def default_params(**kw):
+    p = Params()
+    load().ctcfa_default_params(ctypes.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise ValueError(f"unknown parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+class Engine:
+    """One per (process, device): wraps ``ctcfa_engine`` (owns a HIP stream)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        rc = self._lib.ctcfa_engine_create(ctypes.byref(h), int(device))
+        if rc != OK:
+            msg = self._lib.ctcfa_last_error(None).decode()
+            raise NativeLibraryError(f"ctcfa_engine_create failed ({rc}): {msg}")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ctcfa_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            msg = self._lib.ctcfa_last_error(self._h).decode()
+            exc = NotImplementedError if rc == ERR_UNSUPPORTED else (ValueError if rc == ERR_INVALID else NativeLibraryError)
+            raise exc(f"{what} failed ({rc}): {msg}")
+
+    def align_batch(self, params, lpz_list, labels_list, utt_begin_list=None, want_state=True):
+        """Host-buffer entry ``ctcfa_align_batch``.
+
+        lpz_list: fp32 [T_b, V]; labels_list: int [C_b] (ground_truth_mat[:, 0]);
+        utt_begin_list: int [U_b + 1] or None.  Returns a dict of concatenated outputs plus
+        per-segment views.
+        """
+        B = len(lpz_list)
+        V = int(lpz_list[0].shape[1])
+        T = _i32([l.shape[0] for l in lpz_list])
+        C = _i32([len(g) for g in labels_list])
+        lpz = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in lpz_list]))
+        labels = _i32(np.concatenate([np.asarray(g).reshape(-1) for g in labels_list]))
+        have_utt = utt_begin_list is not None
+        U = _i32([len(u) - 1 for u in utt_begin_list]) if have_utt else None
+        ub = _i32(np.concatenate([np.asarray(u).reshape(-1) for u in utt_begin_list])) if have_utt else None
+        nT, nC = int(T.sum()), int(C.sum())
+        nU = int(U.sum()) if have_utt else 0
+        fol = np.zeros(nC, np.int32)
+        cp = np.zeros(nT, np.float32)
+        state = np.zeros(nT, np.int32) if want_state else None
+        seg = np.zeros((3, max(nU, 1)), np.float64) if have_utt else None
+        t_end = np.zeros(B, np.int32)
+        status = np.zeros(B, np.int32)
+        rc = self._lib.ctcfa_align_batch(
+            self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U), _ptr(lpz), _ptr(labels),
+            _ptr(ub), _ptr(fol), _ptr(cp), _ptr(state),
+            _ptr(seg[0]) if have_utt else None, _ptr(seg[1]) if have_utt else None,
+            _ptr(seg[2]) if have_utt else None, _ptr(t_end), _ptr(status))
+        self._check(rc, "ctcfa_align_batch")
+        t_off = np.concatenate([[0], np.cumsum(T)])
+        c_off = np.concatenate([[0], np.cumsum(C)])
+        u_off = np.concatenate([[0], np.cumsum(U)]) if have_utt else None
+        out = []
+        for b in range(B):
+            d = dict(status=int(status[b]), t_end=int(t_end[b]),
+                     frame_of_label=fol[c_off[b]:c_off[b + 1]], char_prob=cp[t_off[b]:t_off[b + 1]])
+            if want_state:
+                d["state"] = state[t_off[b]:t_off[b + 1]]
+            if have_utt:
+                d["seg_start"] = seg[0][u_off[b]:u_off[b + 1]]
+                d["seg_end"] = seg[1][u_off[b]:u_off[b + 1]]
+                d["seg_score"] = seg[2][u_off[b]:u_off[b + 1]]
+            out.append(d)
+        return out
+
+    def plan(self, params, vocab, T, C, U=None, force_cols_per_lane=0):
+        return Plan(self, params, vocab, T, C, U, force_cols_per_lane)
+
+
+class Plan:
+    """Batch geometry + HBM workspace (``ctcfa_plan``); run it on device-resident buffers."""
+
+    def __init__(self, engine, params, vocab, T, C, U=None, force_cols_per_lane=0):
+        self._eng = engine
+        self._lib = engine._lib
+        T, C = _i32(T), _i32(C)
+        U = _i32(U) if U is not None else None
+        h = ctypes.c_void_p()
+        rc = self._lib.ctcfa_plan_create(engine._h, ctypes.byref(h), ctypes.byref(params), len(T), int(vocab),
+                                         _i32p(T), _i32p(C), _i32p(U), int(force_cols_per_lane))
+        engine._check(rc, "ctcfa_plan_create")
+        self._h = h
+        self.T, self.C, self.U = T, C, U
+        info = PlanInfo()
+        self._lib.ctcfa_plan_get_info(h, ctypes.byref(info))
+        self.info = info.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ctcfa_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, slots):
+        """Keep HIP-event timings of the last ``slots`` runs (0 switches recording off)."""
+        self._eng._check(self._lib.ctcfa_plan_set_timing(self._h, int(slots)), "ctcfa_plan_set_timing")
+
+    def get_timings(self, n):
+        """-> (fill_ms[n], backtrack_ms[n]) of the last n runs (synchronises on them)."""
+        a = (ctypes.c_float * n)()
+        b = (ctypes.c_float * n)()
+        self._eng._check(self._lib.ctcfa_plan_get_timings(self._h, int(n), a, b), "ctcfa_plan_get_timings")
+        return np.array(a[:], np.float64), np.array(b[:], np.float64)
+
+    def run_device(self, d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start,
+                   d_seg_end, d_seg_score, d_t_end, d_status, stream=None):
+        """All arguments are raw device addresses (ints) or None; ``stream`` a hipStream_t value."""
+        args = [d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start, d_seg_end,
+                d_seg_score, d_t_end, d_status, stream]
+        rc = self._lib.ctcfa_plan_run_device(self._h, *[ctypes.c_void_p(a) if a else None for a in args])
+        self._eng._check(rc, "ctcfa_plan_run_device")

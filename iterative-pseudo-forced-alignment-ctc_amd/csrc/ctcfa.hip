@@ -1,0 +1,467 @@
+// ctcfa.hip -- C ABI (include/ctcfa.h) of the gfx950 CTC forced-alignment engine.
+//
+// Host side of the hot path: batch geometry ("plan"), workspace in HBM, kernel
+// selection and launch.  No CPU compute path exists in this library: every entry
+// that aligns needs a HIP device.  Reference interfaces replaced: see include/ctcfa.h.
+#include "ctcfa_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ctcfa.h"
+
+using ctcfa::BtParams;
+using ctcfa::SegDesc;
+
+struct ctcfa_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int lds_limit = 160 * 1024;
+    int num_cu = 256;
+};
+
+struct ctcfa_plan {
+    ctcfa_engine* eng = nullptr;
+    ctcfa_params prm{};
+    int B = 0, V = 0, K = 0, W = 0, VP = 0;
+    int lds_fill = 0, lds_bt = 0, nblk_max = 0;
+    bool have_utt = false;
+    std::vector<SegDesc> segs;
+    int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
+    SegDesc* d_segs = nullptr;
+    uint32_t* d_bits = nullptr;
+    float* d_lastcol = nullptr;
+    // event ring: 3 events per recorded run (start, after fill, after backtrack)
+    std::vector<hipEvent_t> ev;
+    int ev_slots = 0;
+    int64_t ev_runs = 0;
+    void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int) = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(ctcfa_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(eng, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return set_err(eng, CTCFA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int);
+
+template <int VP, int EPT>
+FillFn fill_for_k(int K) {
+    switch (K) {
+        case 1: return ctcfa::fill_kernel<1, VP, EPT>;
+        case 2: return ctcfa::fill_kernel<2, VP, EPT>;
+        case 3: return ctcfa::fill_kernel<3, VP, EPT>;
+        case 4: return ctcfa::fill_kernel<4, VP, EPT>;
+        case 5: return ctcfa::fill_kernel<5, VP, EPT>;
+        case 6: return ctcfa::fill_kernel<6, VP, EPT>;
+        case 8: return ctcfa::fill_kernel<8, VP, EPT>;
+        case 10: return ctcfa::fill_kernel<10, VP, EPT>;
+        case 12: return ctcfa::fill_kernel<12, VP, EPT>;
+        case 16: return ctcfa::fill_kernel<16, VP, EPT>;
+        default: return nullptr;
+    }
+}
+
+// Staging shape: the first NST = 32*VP/EPT threads stage; NST <= 64*W must hold.
+int ept_for(int VP, int W) {
+    const int nst_max = 64 * (W >= 4 ? 4 : (W >= 2 ? 2 : 1));
+    const int ept = ctcfa::kRows * VP / nst_max;
+    return ept < 4 ? 4 : ept;  // 4, 8 or 16; > 16 means the shape is not allowed
+}
+
+FillFn select_fill(int K, int VP, int EPT) {
+    switch (VP * 100 + EPT) {
+        case 3204: return fill_for_k<32, 4>(K);
+        case 3208: return fill_for_k<32, 8>(K);
+        case 3216: return fill_for_k<32, 16>(K);
+        case 6408: return fill_for_k<64, 8>(K);
+        case 6416: return fill_for_k<64, 16>(K);
+        case 12816: return fill_for_k<128, 16>(K);
+        default: return nullptr;
+    }
+}
+
+const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+
+int lds_bytes_fill(int W, int VP) {
+    return (W + 1) * ctcfa::kRows * (VP + 1) * 8 + (W + 1) * ctcfa::kBnd * 4;
+}
+
+int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// Launch-shape heuristic: enough waves to give every SIMD >= 2 (a lone wave issues one
+// VALU per 4 cycles, two share the SIMD at 2), then the widest lane tile (fewest
+// per-row fixed costs), then the least padding.
+bool pick_shape(int B, int Cmax, int VP, int lds_limit, int force_k, int* K_out, int* W_out) {
+    const long target_waves = 2048;
+    double best_score = -1.0;
+    int bestK = 0, bestW = 0;
+    for (int K : kKs) {
+        if (force_k && K != force_k) continue;
+        const int padded = roundup(Cmax, K);
+        const int W = (padded + 64 * K - 1) / (64 * K);
+        if (W > 16 || (K >= 10 && W > 4)) continue;  // K >= 10 kernels are built for <= 256 threads
+        if (ept_for(VP, W) > 16) continue;           // too few waves to stage a wide vocabulary
+        if (lds_bytes_fill(W, VP) > lds_limit) continue;
+        const double fill = (double)Cmax / (64.0 * K * W);           // useful lanes
+        const double amort = (9.0 * K) / (9.0 * K + 5.0);             // per-row fixed cost
+        const long waves = (long)B * W;
+        const double occ = std::min(1.0, (double)waves / (double)target_waves);
+        const double score = fill * amort * occ;
+        if (score > best_score) {
+            best_score = score;
+            bestK = K;
+            bestW = W;
+        }
+    }
+    if (!bestK) return false;
+    *K_out = bestK;
+    *W_out = bestW;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctcfa_version(void) { return CTCFA_VERSION; }
+
+const char* ctcfa_status_string(int s) {
+    switch (s) {
+        case CTCFA_ST_OK: return "ok";
+        case CTCFA_ST_AUDIO_SHORTER_THAN_TEXT: return "Audio is shorter than text!";
+        case CTCFA_ST_BACKTRACK_FAILED: return "backtrack left the trellis (IndexError in ctc_segmentation)";
+        case CTCFA_ST_WINDOWED_UNSUPPORTED: return "T > min_window_size: windowed DP regime not supported";
+        default: return "unknown status";
+    }
+}
+
+void ctcfa_default_params(ctcfa_params* p) {
+    if (!p) return;
+    p->blank = 0;
+    p->flags = CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO;
+    p->min_window_size = 8000;
+    p->max_window_size = 100000;
+    p->score_min_mean_over_L = 30;
+    p->reserved = 0;
+    p->index_duration = 0.025;
+}
+
+int ctcfa_engine_create(ctcfa_engine** out, int device) {
+    if (!out) return set_err(nullptr, CTCFA_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(nullptr, CTCFA_ERR_HIP,
+                       "no HIP device: this library has no CPU fallback (hipGetDeviceCount)");
+    if (device < 0 || device >= n) return set_err(nullptr, CTCFA_ERR_INVALID, "device out of range");
+    ctcfa_engine* eng = new ctcfa_engine();
+    eng->device = device;
+    HIP_TRY(eng, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(eng, hipGetDeviceProperties(&prop, device));
+    eng->num_cu = prop.multiProcessorCount;
+    eng->lds_limit = (int)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 160 * 1024);
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos &&
+        !std::getenv("CTCFA_ALLOW_ANY_ARCH")) {
+        std::string m = std::string("device arch ") + prop.gcnArchName + " is not gfx950";
+        delete eng;
+        return set_err(nullptr, CTCFA_ERR_UNSUPPORTED, m);
+    }
+    HIP_TRY(eng, hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+    *out = eng;
+    return CTCFA_OK;
+}
+
+void ctcfa_engine_destroy(ctcfa_engine* eng) {
+    if (!eng) return;
+    if (eng->stream) (void)hipStreamDestroy(eng->stream);
+    delete eng;
+}
+
+const char* ctcfa_last_error(const ctcfa_engine* eng) { return eng ? eng->err.c_str() : g_err.c_str(); }
+
+void ctcfa_plan_destroy(ctcfa_plan* plan) {
+    if (!plan) return;
+    if (plan->d_segs) (void)hipFree(plan->d_segs);
+    if (plan->d_bits) (void)hipFree(plan->d_bits);
+    if (plan->d_lastcol) (void)hipFree(plan->d_lastcol);
+    for (auto& e : plan->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete plan;
+}
+
+int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
+                      int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
+                      int32_t force_k) {
+    if (!eng || !out || !params || !T || !C) return set_err(eng, CTCFA_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (batch <= 0 || vocab <= 0) return set_err(eng, CTCFA_ERR_INVALID, "batch and vocab must be positive");
+    if (params->blank < 0 || params->blank >= vocab) return set_err(eng, CTCFA_ERR_INVALID, "blank outside vocabulary");
+    if (!(params->index_duration > 0.0)) return set_err(eng, CTCFA_ERR_INVALID, "index_duration must be > 0");
+    if (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero (gratis_blank) is not supported yet");
+    if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > 128)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1,128]");
+    if (vocab > 128) return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128 (token-level vocabularies) not supported yet");
+    HIP_TRY(eng, hipSetDevice(eng->device));
+
+    ctcfa_plan* pl = new ctcfa_plan();
+    pl->eng = eng;
+    pl->prm = *params;
+    pl->B = batch;
+    pl->V = vocab;
+    pl->VP = vocab <= 32 ? 32 : (vocab <= 64 ? 64 : 128);
+    pl->have_utt = (U != nullptr);
+
+    int Cmax = 2, Tmax = 1;
+    for (int b = 0; b < batch; ++b) {
+        if (T[b] < 1 || C[b] < 2 || (U && U[b] < 0)) {
+            delete pl;
+            return set_err(eng, CTCFA_ERR_INVALID, "need T >= 1, C >= 2 ([-1, ..., blank]) and U >= 0");
+        }
+        Cmax = std::max(Cmax, (int)C[b]);
+        Tmax = std::max(Tmax, (int)T[b]);
+    }
+    if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, force_k, &pl->K, &pl->W)) {
+        delete pl;
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
+    }
+    pl->fill_fn = select_fill(pl->K, pl->VP, ept_for(pl->VP, pl->W));
+    if (!pl->fill_fn) {
+        delete pl;
+        return set_err(eng, CTCFA_ERR_INVALID, "unsupported cols_per_lane");
+    }
+    const int K = pl->K, W = pl->W;
+    const int64_t Cpad = 64LL * K * W;
+    pl->lds_fill = lds_bytes_fill(W, pl->VP);
+    pl->segs.resize(batch);
+    int64_t lpz_off = 0, lab_off = 0, frm_off = 0, utt_off = 0, bits_off = 0;
+    for (int b = 0; b < batch; ++b) {
+        SegDesc& s = pl->segs[b];
+        s.lpz_off = lpz_off;
+        s.lab_off = lab_off;
+        s.frm_off = frm_off;
+        s.utt_off = utt_off;
+        s.bits_off = bits_off;
+        s.T = T[b];
+        s.C = C[b];
+        s.U = U ? U[b] : 0;
+        s.shift = (K - 1) - ((C[b] - 1) % K);
+        s.seg_index = b;
+        s.prestatus = CTCFA_ST_OK;
+        if (C[b] > T[b]) s.prestatus = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
+        else if (T[b] > params->min_window_size) s.prestatus = CTCFA_ST_WINDOWED_UNSUPPORTED;
+        const int nblk = (T[b] - 1 + ctcfa::kRows - 1) / ctcfa::kRows;
+        pl->nblk_max = std::max(pl->nblk_max, nblk);
+        lpz_off += (int64_t)T[b] * vocab;
+        lab_off += C[b];
+        frm_off += T[b];
+        utt_off += s.U;
+        if (s.prestatus == CTCFA_ST_OK) bits_off += (int64_t)nblk * Cpad;
+        // 4TV + TC/8 + 4T + 8C + 4T
+        pl->alg_bytes += 4LL * T[b] * vocab + (int64_t)T[b] * C[b] / 8 + 4LL * T[b] + 8LL * C[b] + 4LL * T[b];
+    }
+    pl->total_T = frm_off;
+    pl->total_C = lab_off;
+    pl->total_U = utt_off;
+    pl->bits_words = bits_off;
+    pl->lds_bt = std::max(1, pl->nblk_max) * 8;
+    if (pl->lds_bt > eng->lds_limit) {
+        delete pl;
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "segment too long for the backtrack record buffer");
+    }
+
+#define PLAN_TRY(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            std::string m = std::string(#expr) + ": " + hipGetErrorString(_e);                \
+            ctcfa_plan_destroy(pl);                                                           \
+            return set_err(eng, _e == hipErrorOutOfMemory ? CTCFA_ERR_NOMEM : CTCFA_ERR_HIP, m); \
+        }                                                                                     \
+    } while (0)
+    PLAN_TRY(hipMalloc(&pl->d_segs, sizeof(SegDesc) * (size_t)batch));
+    PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
+    PLAN_TRY(hipMalloc(&pl->d_bits, sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
+    PLAN_TRY(hipMalloc(&pl->d_lastcol, sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+    if (pl->lds_fill > 48 * 1024)
+        PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
+    if (pl->lds_bt > 48 * 1024)
+        PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ctcfa::backtrack_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
+#undef PLAN_TRY
+    *out = pl;
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
+    if (!pl || !info) return CTCFA_ERR_INVALID;
+    info->batch = pl->B;
+    info->cols_per_lane = pl->K;
+    info->waves_per_seg = pl->W;
+    info->vocab_pitch = pl->VP + 1;
+    info->lds_bytes = pl->lds_fill;
+    info->n_blocks_max = pl->nblk_max;
+    info->workspace_bytes = pl->bits_words * 4 + pl->total_T * 4;
+    info->algorithmic_bytes = pl->alg_bytes;
+    info->total_frames = pl->total_T;
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_set_timing(ctcfa_plan* pl, int slots) {
+    if (!pl || slots < 0 || slots > 4096) return CTCFA_ERR_INVALID;
+    ctcfa_engine* eng = pl->eng;
+    for (auto& e : pl->ev)
+        if (e) (void)hipEventDestroy(e);
+    pl->ev.assign((size_t)slots * 3, nullptr);
+    pl->ev_slots = slots;
+    pl->ev_runs = 0;
+    for (auto& e : pl->ev) HIP_TRY(eng, hipEventCreate(&e));
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_labels,
+                          const int32_t* d_utt_begin, int32_t* d_fol, float* d_char_prob,
+                          int32_t* d_state, double* d_seg_start, double* d_seg_end,
+                          double* d_seg_score, int32_t* d_t_end, int32_t* d_status, void* stream) {
+    if (!pl) return CTCFA_ERR_INVALID;
+    ctcfa_engine* eng = pl->eng;
+    if (!d_lpz || !d_labels || !d_fol || !d_char_prob || !d_t_end || !d_status)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL device buffer");
+    const bool want_seg = d_utt_begin && d_seg_start && d_seg_end && d_seg_score;
+    if (want_seg && !pl->have_utt) return set_err(eng, CTCFA_ERR_INVALID, "plan was created without U[]");
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
+
+    hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 3] : nullptr;
+    if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->W), pl->lds_fill, st, pl->d_segs, d_lpz,
+                       d_labels, pl->d_bits, pl->d_lastcol, pl->V, pl->prm.blank,
+                       (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0);
+    HIP_TRY(eng, hipGetLastError());
+    if (ev) HIP_TRY(eng, hipEventRecord(ev[1], st));
+    BtParams bp;
+    bp.V = pl->V;
+    bp.blank = pl->prm.blank;
+    bp.Cpad = 64 * pl->K * pl->W;
+    bp.flags = pl->prm.flags;
+    bp.L = pl->prm.score_min_mean_over_L;
+    bp.dur = pl->prm.index_duration;
+    hipLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(64), pl->lds_bt, st, pl->d_segs, d_lpz,
+                       d_labels, want_seg ? d_utt_begin : nullptr, pl->d_bits, pl->d_lastcol, bp, d_fol,
+                       d_char_prob, d_state, d_seg_start, d_seg_end, want_seg ? d_seg_score : nullptr,
+                       d_t_end, d_status);
+    HIP_TRY(eng, hipGetLastError());
+    if (ev) {
+        HIP_TRY(eng, hipEventRecord(ev[2], st));
+        pl->ev_runs++;
+    }
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_get_timings(ctcfa_plan* pl, int n, float* fill_ms, float* backtrack_ms) {
+    if (!pl || n <= 0 || !pl->ev_slots || n > pl->ev_slots || n > pl->ev_runs) return CTCFA_ERR_INVALID;
+    ctcfa_engine* eng = pl->eng;
+    for (int i = 0; i < n; ++i) {
+        const int64_t run = pl->ev_runs - n + i;
+        hipEvent_t* ev = &pl->ev[(size_t)(run % pl->ev_slots) * 3];
+        HIP_TRY(eng, hipEventSynchronize(ev[2]));
+        float a = 0.f, b = 0.f;
+        HIP_TRY(eng, hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(eng, hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (fill_ms) fill_ms[i] = a;
+        if (backtrack_ms) backtrack_ms[i] = b;
+    }
+    return CTCFA_OK;
+}
+
+int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                      const int32_t* T, const int32_t* C, const int32_t* U, const float* lpz,
+                      const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label,
+                      float* char_prob, int32_t* state, double* seg_start, double* seg_end,
+                      double* seg_score, int32_t* t_end, int32_t* status) {
+    if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
+    if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
+    ctcfa_plan* pl = nullptr;
+    int rc = ctcfa_plan_create(eng, &pl, params, batch, vocab, T, C, U, 0);
+    if (rc != CTCFA_OK) return rc;
+    const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
+    const size_t n_lpz = (size_t)pl->total_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
+    const size_t n_utt = (size_t)pl->total_U, n_ub = n_utt + batch;
+    float *d_lpz = nullptr, *d_cp = nullptr;
+    int32_t *d_lab = nullptr, *d_ub = nullptr, *d_fol = nullptr, *d_state = nullptr, *d_tend = nullptr, *d_status = nullptr;
+    double* d_seg = nullptr;
+    hipStream_t st = eng->stream;
+    auto cleanup = [&]() {
+        (void)hipFree(d_lpz); (void)hipFree(d_cp); (void)hipFree(d_lab); (void)hipFree(d_ub);
+        (void)hipFree(d_fol); (void)hipFree(d_state); (void)hipFree(d_tend); (void)hipFree(d_status);
+        (void)hipFree(d_seg);
+        ctcfa_plan_destroy(pl);
+    };
+#define AB_TRY(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            std::string m = std::string(#expr) + ": " + hipGetErrorString(_e);            \
+            cleanup();                                                                    \
+            return set_err(eng, CTCFA_ERR_HIP, m);                                        \
+        }                                                                                 \
+    } while (0)
+    AB_TRY(hipMalloc(&d_lpz, n_lpz * sizeof(float)));
+    AB_TRY(hipMalloc(&d_lab, n_lab * sizeof(int32_t)));
+    AB_TRY(hipMalloc(&d_fol, n_lab * sizeof(int32_t)));
+    AB_TRY(hipMalloc(&d_cp, n_frm * sizeof(float)));
+    if (state) AB_TRY(hipMalloc(&d_state, n_frm * sizeof(int32_t)));
+    AB_TRY(hipMalloc(&d_tend, batch * sizeof(int32_t)));
+    AB_TRY(hipMalloc(&d_status, batch * sizeof(int32_t)));
+    if (want_seg) {
+        AB_TRY(hipMalloc(&d_ub, n_ub * sizeof(int32_t)));
+        AB_TRY(hipMalloc(&d_seg, 3 * n_utt * sizeof(double)));
+        AB_TRY(hipMemcpyAsync(d_ub, utt_begin, n_ub * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    AB_TRY(hipMemcpyAsync(d_lpz, lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
+    AB_TRY(hipMemcpyAsync(d_lab, labels, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    rc = ctcfa_plan_run_device(pl, d_lpz, d_lab, d_ub, d_fol, d_cp, d_state, d_seg,
+                               d_seg ? d_seg + n_utt : nullptr, d_seg ? d_seg + 2 * n_utt : nullptr, d_tend,
+                               d_status, st);
+    if (rc != CTCFA_OK) {
+        cleanup();
+        return rc;
+    }
+    AB_TRY(hipMemcpyAsync(frame_of_label, d_fol, n_lab * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AB_TRY(hipMemcpyAsync(char_prob, d_cp, n_frm * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (state) AB_TRY(hipMemcpyAsync(state, d_state, n_frm * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AB_TRY(hipMemcpyAsync(t_end, d_tend, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AB_TRY(hipMemcpyAsync(status, d_status, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (want_seg) {
+        AB_TRY(hipMemcpyAsync(seg_start, d_seg, n_utt * sizeof(double), hipMemcpyDeviceToHost, st));
+        AB_TRY(hipMemcpyAsync(seg_end, d_seg + n_utt, n_utt * sizeof(double), hipMemcpyDeviceToHost, st));
+        AB_TRY(hipMemcpyAsync(seg_score, d_seg + 2 * n_utt, n_utt * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    AB_TRY(hipStreamSynchronize(st));
+#undef AB_TRY
+    cleanup();
+    return CTCFA_OK;
+}
+
+}  // extern "C"

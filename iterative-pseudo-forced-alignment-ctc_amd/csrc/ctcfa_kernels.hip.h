@@ -1,0 +1,451 @@
+// ctcfa_kernels.hip.h -- gfx950 device code of the CTC forced-alignment engine.
+//
+// What is computed (per segment, S = 1 labels, un-windowed regime T <= min_window_size):
+//   table[t,c] = max( table[t-1,c-1] + lpz[t,g_c],  table[t-1,c] + max(lpz[t,blank], lpz[t,g_c]),  -1e9 )
+// in fp32, exactly the recurrence of ctc-segmentation 1.7.1's cython_fill_table
+// (requirements.txt:13; reached from src/iterative_utterance_alignment.py:216), plus the
+// transition the package's backtrack would infer at (t,c) from fp32 residuals:
+//   SWITCH  iff  | max(lb,e) - (table[t,c]-table[t-1,c]) |  >  | e - (table[t,c]-table[t-1,c-1]) |
+// That predicate is evaluated at fill time, while all four operands are in registers,
+// and kept as ONE BIT per cell; the fp32 trellis itself never leaves the chip.
+//
+// Mapping (CDNA4, 64-wide waves, no MFMA: this is a max-plus scan, not a contraction):
+//   * one workgroup per segment, W waves; wave w owns padded columns [w*64K, (w+1)*64K),
+//     lane l owns K consecutive columns -> the c-1 neighbour is in-lane for k>0 and one
+//     DPP wave_shr:1 for k==0; lane 0 takes the previous wave's last column from LDS;
+//   * time runs in blocks of R=32 rows; wave w works on block (s - w) in step s (a skewed
+//     pipeline, one s_barrier per step) so that the cross-wave dependency is a block old;
+//   * emission rows are staged once per workgroup through an LDS ring as (e, m) pairs,
+//     m = max(lb, e, -1e9), row pitch VP+1 entries: a gather is one ds_read_b64 whose
+//     32 x 8 B row covers all 64 banks exactly once -> conflict-free for any label mix;
+//     entry VP is the "start column" pseudo-label (e = -inf, m = 0) that makes column 0
+//     (ground_truth == -1) and the left padding reproduce table[t,0];
+//   * decisions are shifted into a per-(lane,k) register (v_alignbit) and stored every
+//     32 rows as words bits[block][column]; HBM traffic per segment is
+//     4*T*V (emissions, once) + T*Cpad/8 (bits) + 4*T (last-column scores).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ctcfa {
+
+constexpr int kRows = 32;      // rows per block == bits per decision word
+constexpr int kBnd = 128;      // ring length (rows) of the cross-wave boundary column
+constexpr float kProbMax = -1000000000.0f;   // Cython sentinel (prob_max)
+constexpr float kMaxProb = -10000000000.0f;  // config.max_prob on the NumPy side
+
+struct SegDesc {
+    int64_t lpz_off;   // elements into lpz
+    int64_t lab_off;   // elements into labels / frame_of_label
+    int64_t frm_off;   // elements into char_prob / state / lastcol
+    int64_t utt_off;   // elements into seg_*; utt_begin is at utt_off + b
+    int64_t bits_off;  // words into the decision-bit workspace
+    int32_t T, C, U;
+    int32_t shift;      // left padding so that column C-1 lands on k == K-1
+    int32_t prestatus;  // 0, or the status decided from shapes alone
+    int32_t seg_index;
+};
+
+__device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) {
+    // lane i <- src[lane i-1]; lane 0 keeps `old_lane0` (bound_ctrl off)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_lane0),
+                                                      __float_as_int(src), 0x138, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fill kernel.  grid = B workgroups, block = 64*W threads, dynamic LDS =
+//   (W+1) * kRows * (VP+1) * 8   (emission ring)  +  (W+1) * kBnd * 4  (boundary columns)
+// ---------------------------------------------------------------------------------------
+// EPT = staged elements per staging thread per block (4, 8 or 16): the first
+// NST = kRows*VP/EPT threads of the workgroup stage, each exactly EPT rows of one
+// vocabulary entry, so the prefetch registers are a fixed-size array with no predication.
+template <int K, int VP, int EPT>
+__global__ void __launch_bounds__((K >= 10) ? 256 : 1024)
+fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
+            const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
+            float* __restrict__ lastcol, int V, int blank, int preamble) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int PITCH = VP + 1;
+    constexpr int SLOT_BYTES = kRows * PITCH * 8;
+    constexpr int NST = kRows * VP / EPT;  // staging threads (multiple of 64 and of VP)
+    constexpr int RSTEP = NST / VP;        // row stride of one staging thread
+    static_assert(NST % 64 == 0 && NST % VP == 0 && RSTEP * EPT == kRows, "staging shape");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = blockDim.x >> 6;
+    const int nthreads = blockDim.x;
+    const int NS = W + 1;
+
+    const SegDesc sd = segs[blockIdx.x];
+    if (sd.prestatus != 0) return;  // uniform: nothing to fill
+    const int T = sd.T, C = sd.C, shift = sd.shift;
+    const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
+
+    float* bnd = reinterpret_cast<float*>(smem + NS * SLOT_BYTES);  // [(W+1)][kBnd]
+    const int nblk = (T - 1 + kRows - 1) / kRows;
+    const int Cpad = 64 * K * W;
+    const int nsteps = nblk + W - 1;
+
+    // ---- per-lane column setup ----------------------------------------------------------
+    float prev[K];
+    uint32_t dec[K];
+    uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair in row 0 of the current slot
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int pc = (w * 64 + lane) * K + k;
+        const int c = pc - shift;
+        int lab;
+        if (c <= 0) lab = VP;                  // start column / left padding
+        else if (c < C) lab = seg_lab[c];
+        else lab = blank;                      // right padding: any valid entry
+        gaddr[k] = static_cast<uint32_t>(lab) * 8u;
+        prev[k] = (c <= 0) ? 0.0f : kProbMax;  // table[0,0] = 0, table[0,c>0] = -1e9
+        dec[k] = 0u;
+    }
+    const int pcl = C - 1 + shift;  // padded index of the last label column
+    const bool owns_last = (w == pcl / (64 * K)) && (lane == (pcl % (64 * K)) / K);
+
+    for (int i = tid; i < (W + 1) * kBnd; i += nthreads) bnd[i] = kProbMax;
+
+    // ---- staging: global -> registers -> (e, m) pairs in LDS ----------------------------
+    const bool stager = tid < NST;  // wave-uniform
+    const int sv = tid % VP;
+    const int r0 = tid / VP;
+    const int svc = sv < V ? sv : V - 1;
+    const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
+    float stg[EPT];
+    auto stage_load = [&](int jb) {
+        if (!stager) return;
+        const int t0 = jb * kRows + 1 + r0;
+#pragma unroll
+        for (int it = 0; it < EPT; ++it) {
+            int t = t0 + it * RSTEP;
+            t = t < T ? t : T - 1;  // rows past the end re-read the last row (discarded below)
+            const uint32_t off = static_cast<uint32_t>(t * V + svc) * 4u;
+            stg[it] = *reinterpret_cast<const float*>(lpz_bytes + off);
+        }
+    };
+    auto stage_write = [&](int jb) {
+        if (!stager) return;
+        unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
+        const int t0 = jb * kRows + 1 + r0;
+#pragma unroll
+        for (int it = 0; it < EPT; ++it) {
+            const int r = r0 + it * RSTEP;
+            const int t = t0 + it * RSTEP;
+            const float e = stg[it];
+            float lb;
+            if constexpr (VP <= 64) {
+                lb = __shfl(e, (lane & ~(VP - 1)) + blank);  // the row's blank entry sits in this wave
+            } else {
+                const int tc = t < T ? t : T - 1;
+                lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
+            }
+            const bool valid = t < T;
+            float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
+            if (sv < V) row[sv] = valid ? make_float2(e, max3f(lb, e, kProbMax)) : make_float2(0.f, 0.f);
+            if (sv == 0)
+                row[VP] = make_float2(-__builtin_inff(),
+                                      (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+        }
+    };
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    int cur_slot = 0;  // slot whose offset is folded into gaddr[]
+    for (int s = 0; s < nsteps; ++s) {
+        const bool have_next = (s + 1 < nblk);
+        if (have_next) stage_load(s + 1);
+
+        const int j = s - w;
+        if (j >= 0 && j < nblk) {
+            const int slot = j % NS;
+            const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
+            cur_slot = slot;
+#pragma unroll
+            for (int k = 0; k < K; ++k) gaddr[k] += delta;
+            const int tb = j * kRows + 1;
+            const float* bnd_in = bnd + w * kBnd;
+            float* bnd_out = bnd + (w + 1) * kBnd;
+
+#pragma unroll 2
+            for (int i = 0; i < kRows; ++i) {
+                const int t = tb + i;
+                const float lin = (w == 0) ? 0.0f : bnd_in[(t - 1) & (kBnd - 1)];
+                const float leftv = dpp_wave_shr1(lin, prev[K - 1]);
+                float2 em[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    em[k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + i * (PITCH * 8));
+#pragma unroll
+                for (int k = K - 1; k >= 0; --k) {
+                    const float pl = (k == 0) ? leftv : prev[k > 0 ? k - 1 : 0];
+                    const float pk = prev[k];
+                    const float a = pl + em[k].x;
+                    const float b = pk + em[k].y;
+                    const float nw = max3f(a, b, kProbMax);
+                    const float rsw = em[k].x - (nw - pl);
+                    const float rst = em[k].y - (nw - pk);
+                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
+                    prev[k] = nw;
+                }
+                if (lane == 63) bnd_out[t & (kBnd - 1)] = prev[K - 1];
+                if (owns_last && t < T) seg_lastcol[t] = prev[K - 1];
+            }
+            uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + (w * 64 + lane) * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) bp[k] = dec[k];
+        }
+
+        if (have_next) stage_write(s + 1);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backtrack + per-frame outputs + utterance scoring.  grid = B, block = 64 (one wave).
+// ---------------------------------------------------------------------------------------
+struct BtParams {
+    int V, blank, Cpad;
+    uint32_t flags;
+    int L;            // score_min_mean_over_L
+    double dur;       // index_duration
+};
+
+__device__ __forceinline__ double np_pairwise_sum_le128(const float* __restrict__ a, int n) {
+    // NumPy's pairwise summation for n <= 128 (fp64 accumulate of fp32-exact values)
+    auto ld = [&](int i) {
+        return (double)__hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += ld(i);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = ld(q);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] += ld(i + q);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += ld(i);
+    return res;
+}
+
+__global__ void __launch_bounds__(64)
+backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
+                 const int32_t* __restrict__ labels, const int32_t* __restrict__ utt_begin,
+                 const uint32_t* __restrict__ bits, const float* __restrict__ lastcol,
+                 BtParams p, int32_t* __restrict__ frame_of_label, float* __restrict__ char_prob,
+                 int32_t* __restrict__ state, double* __restrict__ seg_start,
+                 double* __restrict__ seg_end, double* __restrict__ seg_score,
+                 int32_t* __restrict__ t_end_out, int32_t* __restrict__ status_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int2* rec = reinterpret_cast<int2*>(smem);  // per block: (entry column, switch mask)
+    const int lane = threadIdx.x;
+    const SegDesc sd = segs[blockIdx.x];
+    const int T = sd.T, C = sd.C, U = sd.U, shift = sd.shift, V = p.V;
+    const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    int32_t* fol = frame_of_label + sd.lab_off;
+    float* cp = char_prob + sd.frm_off;
+    int32_t* st = state ? state + sd.frm_off : nullptr;
+    const bool want_seg = (utt_begin != nullptr) && (seg_score != nullptr) && U > 0;
+
+    auto fail = [&](int code) {
+        for (int c = lane; c < C; c += 64) fol[c] = 0;
+        for (int t = lane; t < T; t += 64) {
+            cp[t] = 0.0f;
+            if (st) st[t] = -2;
+        }
+        if (want_seg)
+            for (int u = lane; u < U; u += 64) {
+                seg_start[sd.utt_off + u] = 0.0;
+                seg_end[sd.utt_off + u] = 0.0;
+                seg_score[sd.utt_off + u] = 0.0;
+            }
+        if (lane == 0) {
+            status_out[sd.seg_index] = code;
+            t_end_out[sd.seg_index] = -1;
+        }
+    };
+    if (sd.prestatus != 0) {
+        fail(sd.prestatus);
+        return;
+    }
+
+    // ---- end cell: first maximum of the last column (lastMax/lastArgMax of the fill) -----
+    int t_end;
+    {
+        const float* lc = lastcol + sd.frm_off;
+        float bv = kProbMax;  // table[0, C-1]
+        int bt = 0;
+        for (int t = lane; t < T; t += 64) {
+            const float v = (t == 0) ? kProbMax : lc[t];
+            if (t == lane || v > bv) {  // first element initialises, then strict '>'
+                if (t == lane) { bv = v; bt = t; }
+                else { bv = v; bt = t; }
+            }
+        }
+        if (lane >= T) { bv = -__builtin_inff(); bt = 0x7fffffff; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int ot = __shfl_xor(bt, off);
+            if (ov > bv || (ov == bv && ot < bt)) { bv = ov; bt = ot; }
+        }
+        t_end = __builtin_amdgcn_readfirstlane(bt);
+        if (p.flags & 4u) t_end = T - 1;
+    }
+
+    // ---- phase A: scalar walk, one step per run of STAYs (find-first-set on the word) ----
+    const int nblk = (T - 1 + kRows - 1) / kRows;
+    for (int j = lane; j < nblk; j += 64) rec[j] = make_int2(-1, 0);
+    __syncthreads();
+    int pc = C - 1 + shift;
+    int bad = 0;
+    if (t_end >= 1) {
+        int j = (t_end - 1) >> 5;
+        int b0 = 31 - ((t_end - 1) & 31);
+        const uint32_t* seg_bits = bits + sd.bits_off;
+        while (j >= 0) {
+            const int cstart = pc;
+            uint32_t S = 0;
+            if (pc - shift > 0) {
+                const int col = pc - lane;
+                uint32_t wl = 0;
+                if (lane < 32 && col >= 0) wl = seg_bits[(int64_t)j * p.Cpad + col];
+                for (;;) {
+                    uint32_t wv = __builtin_amdgcn_readlane(wl, cstart - pc);
+                    if (pc - shift <= 0) wv = 0;  // start column: always STAY
+                    const uint32_t m = (b0 < 32) ? (wv & (0xffffffffu << b0)) : 0u;
+                    if (m == 0) break;
+                    const int b1 = __builtin_ctz(m);
+                    S |= 1u << b1;
+                    pc -= 1;
+                    b0 = b1 + 1;
+                    if (b0 >= 32) break;
+                }
+            }
+            if (lane == 0) rec[j] = make_int2(cstart, (int)S);
+            --j;
+            b0 = 0;
+        }
+        if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
+    } else {
+        bad = (pc - shift > 0);
+    }
+    if (bad) {
+        fail(2);
+        return;
+    }
+    __syncthreads();
+
+    // ---- phase B: per-frame outputs, lanes = frames -----------------------------------
+    for (int c = lane; c < C; c += 64) fol[c] = 0;
+    __syncthreads();
+    for (int t = lane; t < T; t += 64) {
+        float prob = 0.0f;
+        int s_lab = -2;
+        if (t >= 1 && t <= t_end) {
+            const int j = (t - 1) >> 5;
+            const int b = 31 - ((t - 1) & 31);
+            const int2 r = rec[j];
+            const uint32_t S = (uint32_t)r.y;
+            const int pct = r.x - __builtin_popcount(S & ((1u << b) - 1u));
+            const int sw = (S >> b) & 1u;
+            const int c = pct - shift;
+            const float lb = seg_lpz[(int64_t)t * V + p.blank];
+            if (c <= 0) {
+                prob = __builtin_fmaxf(lb, kMaxProb);
+                s_lab = -1;
+            } else {
+                const int g = seg_lab[c];
+                const float e = seg_lpz[(int64_t)t * V + g];
+                const float mx = __builtin_fmaxf(e, kMaxProb);
+                if (sw) {
+                    prob = mx;
+                    s_lab = g;
+                    fol[c] = t;
+                } else {
+                    prob = (mx > lb) ? mx : lb;
+                    s_lab = -1;
+                }
+            }
+        }
+        cp[t] = prob;
+        if (st) st[t] = s_lab;
+    }
+    if (lane == 0) {
+        status_out[sd.seg_index] = 0;
+        t_end_out[sd.seg_index] = t_end;
+    }
+    if (!want_seg) return;
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase C: determine_utterance_segments, lanes = window starts ------------------
+    const int32_t* ub = utt_begin + sd.utt_off + sd.seg_index;
+    auto tim = [&](int c) {
+        if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
+        return (double)__hip_atomic_load(fol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * p.dur;
+    };
+    const int n = p.L;
+    for (int u = 0; u < U; ++u) {
+        const int b = ub[u], e = ub[u + 1];
+        const double mid_b = (tim(b) + tim(b - 1)) / 2;
+        const double sb = tim(b + 1) - 0.5;
+        const double start = (mid_b > sb) ? mid_b : sb;  // max(timings[b+1]-0.5, middle)
+        const double mid_e = (tim(e) + tim(e - 1)) / 2;
+        const double ee = tim(e - 1) + 0.5;
+        const double end = (mid_e < ee) ? mid_e : ee;  // min(timings[e-1]+0.5, middle)
+        const long long start_t = (long long)rint(start / p.dur);
+        const long long end_t = (long long)rint(end / p.dur);
+        double min_avg;
+        if (end_t <= start_t) {
+            min_avg = -10000000000.0;
+        } else if (end_t - start_t <= n) {
+            long long lo = start_t < 0 ? 0 : start_t, hi = end_t > T ? T : end_t;
+            if (lo > T) lo = T;
+            if (hi < lo) hi = lo;
+            min_avg = np_pairwise_sum_le128(cp + lo, (int)(hi - lo)) / (double)(hi - lo);
+        } else {
+            double local = 0.0;
+            for (long long t0 = start_t + lane; t0 < end_t - n; t0 += 64) {
+                long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
+                if (lo > T) lo = T;
+                if (hi < lo) hi = lo;
+                const double m = np_pairwise_sum_le128(cp + lo, (int)(hi - lo)) / (double)(hi - lo);
+                if (m < local) local = m;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(local, off);
+                if (o < local) local = o;
+            }
+            min_avg = local;
+        }
+        if (lane == 0) {
+            seg_start[sd.utt_off + u] = start;
+            seg_end[sd.utt_off + u] = end;
+            seg_score[sd.utt_off + u] = min_avg;
+        }
+    }
+}
+
+}  // namespace ctcfa

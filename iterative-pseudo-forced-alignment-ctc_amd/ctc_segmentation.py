@@ -1,0 +1,222 @@
+"""Host mirror of the ``ctc_segmentation`` package surface the reference depends on.
+
+The reference never imports ``ctc_segmentation`` directly; it reaches it through
+SpeechBrain's wrapper (``speechbrain.alignment.ctc_segmentation``, imported at
+/root/reference/src/iterative_utterance_alignment.py:11, word_level_alignment.py:8,
+search_on_speech.py:9) and configures it through the parameter names listed at
+/root/reference/src/test/test_ctc_segmentation.py:20-38.  This module keeps those
+names and argument meanings (``ctc-segmentation==1.7.1``, requirements.txt:13):
+
+* ``CtcSegmentationParameters``   -- same fields and defaults;
+* ``prepare_token_list`` / ``prepare_text`` -- text -> label matrix (host work, negligible);
+* ``ctc_segmentation(config, lpz, ground_truth)`` -- table fill + backtrack, executed by the
+  HIP kernels behind the C ABI (``include/ctcfa.h``); raises ``AssertionError`` when the
+  text is longer than the audio, as the package does (caught by the reference at
+  iterative_utterance_alignment.py:390);
+* ``get_segments_device`` -- fill + backtrack + ``determine_utterance_segments`` in one
+  launch for a batch of segments.
+
+There is no CPU implementation of the DP here: without the HIP library and a GPU these
+functions raise.
+"""
+import numpy as np
+
+from . import _native
+
+
+class CtcSegmentationParameters:
+    """Parameters of the segmentation (names/defaults of ctc-segmentation 1.7.1)."""
+
+    max_prob = -10000000000.0
+    skip_prob = -10000000000.0
+    min_window_size = 8000
+    max_window_size = 100000
+    index_duration = 0.025
+    score_min_mean_over_L = 30
+    space = "·"
+    blank = 0
+    replace_spaces_with_blanks = False
+    blank_transition_cost_zero = False
+    preamble_transition_cost_zero = True
+    backtrack_from_max_t = False
+    self_transition = "ε"
+    start_of_ground_truth = "#"
+    excluded_characters = ".,»«•❍·"
+    tokenized_meta_symbol = "▁"
+    char_list = None
+    subsampling_factor = None
+    frame_duration_ms = None
+
+    def __init__(self, **kwargs):
+        self.set(**kwargs)
+
+    def set(self, **kwargs):
+        for key, value in kwargs.items():
+            if not hasattr(self, key):
+                raise ValueError(f"Parameter {key} is not a CtcSegmentationParameters field")
+            setattr(self, key, value)
+
+    @property
+    def index_duration_in_seconds(self):
+        if self.subsampling_factor and self.frame_duration_ms:
+            return self.frame_duration_ms * self.subsampling_factor / 1000
+        return self.index_duration
+
+    @property
+    def flags(self):
+        return int(self.blank_transition_cost_zero) + 2 * int(self.preamble_transition_cost_zero)
+
+    def __repr__(self):
+        fields = ("min_window_size", "max_window_size", "index_duration", "score_min_mean_over_L",
+                  "blank", "blank_transition_cost_zero", "preamble_transition_cost_zero",
+                  "backtrack_from_max_t")
+        return "CtcSegmentationParameters(" + ", ".join(f"{k}={getattr(self, k)!r}" for k in fields) + ")"
+
+    def to_native(self):
+        """-> ``ctcfa_params`` for the C ABI."""
+        if self.max_prob != -10000000000.0 or self.skip_prob > self.max_prob:
+            raise NotImplementedError("max_prob / skip_prob other than the package defaults")
+        flags = self.flags
+        if self.backtrack_from_max_t:
+            flags |= _native.FLAG_BACKTRACK_FROM_MAX_T
+        return _native.default_params(
+            blank=int(self.blank), flags=flags, min_window_size=int(self.min_window_size),
+            max_window_size=int(self.max_window_size),
+            score_min_mean_over_L=int(self.score_min_mean_over_L),
+            index_duration=float(self.index_duration_in_seconds))
+
+
+def prepare_token_list(config, text):
+    """Token-id utterances -> (ground_truth_mat int64 [C,1], utt_begin_indices).
+
+    ``text`` is a list of 1-D integer arrays.  Layout: ``[-1]``, then for every
+    utterance a separating ``blank`` (unless one is already there) followed by its ids,
+    and a closing ``blank``.  This is the converter SpeechBrain uses for
+    ``text_converter="tokenize"`` (its default; the reference scripts never override it).
+    """
+    blank = config.blank
+    seq = [-1]
+    begins = []
+    for utt in text:
+        if seq[-1] != blank:
+            seq.append(blank)
+        begins.append(len(seq) - 1)
+        seq.extend(int(i) for i in np.asarray(utt).reshape(-1))
+    if seq[-1] != blank:
+        seq.append(blank)
+    begins.append(len(seq) - 1)
+    return np.asarray(seq, dtype=np.int64).reshape(-1, 1), begins
+
+
+def prepare_text(config, text, char_list=None):
+    """Character utterances -> (ground_truth_mat int64 [C,S], utt_begin_indices).
+
+    ``text_converter="classic"``: a ``"#"``-led character string with ``config.space``
+    between utterances; row i of the matrix holds, for s = 0..S-1, the index of the
+    ``char_list`` entry equal to the s+1 characters ending at position i (or -1).
+    """
+    if isinstance(config.blank, str):
+        config.blank = 0
+    if char_list is not None:
+        config.char_list = char_list
+    chars = config.char_list
+    blank_sym = chars[config.blank]
+    gt = config.start_of_ground_truth
+    begins = []
+    for utt in text:
+        if not gt.endswith(config.space):
+            gt += config.space
+        begins.append(len(gt) - 1)
+        for ch in utt:
+            if ch.isspace() and config.replace_spaces_with_blanks:
+                if not gt.endswith(config.space):
+                    gt += config.space
+            elif ch in chars and ch not in config.excluded_characters:
+                gt += ch
+            elif config.tokenized_meta_symbol + ch in chars:
+                gt += ch
+    if not gt.endswith(config.space):
+        gt += config.space
+    begins.append(len(gt) - 1)
+    span_max = max(len(c) for c in chars)
+    index_of = {}
+    for i, c in enumerate(chars):
+        index_of.setdefault(c, i)  # list.index semantics: first match
+    mat = np.full((len(gt), span_max), -1, dtype=np.int64)
+    for i in range(len(gt)):
+        for s in range(span_max):
+            if i - s < 0:
+                continue
+            span = gt[i - s:i + 1].replace(config.space, blank_sym)
+            j = index_of.get(span)
+            if j is not None:
+                mat[i, s] = j
+    return mat, begins
+
+
+_engines = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine for ``device`` (created on first use; needs a GPU)."""
+    eng = _engines.get(device)
+    if eng is None:
+        eng = _engines[device] = _native.Engine(device)
+    return eng
+
+
+def _labels_from_mat(ground_truth):
+    gt = np.asarray(ground_truth)
+    if gt.ndim == 2:
+        if gt.shape[1] != 1:
+            # multi-character tokens (S > 1) need the second kernel variant
+            if (gt[:, 1:] != -1).any():
+                raise NotImplementedError("ground truth with multi-character tokens (S > 1)")
+        gt = gt[:, 0]
+    return np.ascontiguousarray(gt, dtype=np.int32)
+
+
+def _raise_for_status(status):
+    if status == _native.ST_AUDIO_SHORTER_THAN_TEXT:
+        raise AssertionError("Audio is shorter than text!")
+    if status == _native.ST_BACKTRACK_FAILED:
+        raise IndexError("CTC segmentation backtrack left the trellis")
+    if status == _native.ST_WINDOWED_UNSUPPORTED:
+        raise NotImplementedError("lpz longer than min_window_size: windowed DP regime not supported")
+    if status != _native.ST_OK:
+        raise RuntimeError(f"ctcfa status {status}")
+
+
+def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, engine=None, want_state=True):
+    """Batch of segments through the HIP engine -> list of per-segment dicts.
+
+    Each dict: status, t_end, frame_of_label (int32 [C]), char_prob (fp32 [T]),
+    state (int32 [T]: label id | -1 self transition | -2 untouched),
+    seg_start / seg_end / seg_score (fp64 [U]).  No exception for per-segment status.
+    """
+    engine = engine or default_engine()
+    labels = [_labels_from_mat(g) for g in ground_truth_list]
+    lpz_list = [np.ascontiguousarray(l, dtype=np.float32) for l in lpz_list]
+    return engine.align_batch(config.to_native(), lpz_list, labels, utt_begin_list, want_state=want_state)
+
+
+def ctc_segmentation(config, lpz, ground_truth, engine=None):
+    """Fill + backtrack for one segment -> (timings fp64 [C], char_probs fp64 [T], state_list)."""
+    res = get_segments_device(config, [lpz], [ground_truth], None, engine=engine)[0]
+    _raise_for_status(res["status"])
+    timings = res["frame_of_label"].astype(np.int64) * config.index_duration_in_seconds
+    return timings, res["char_prob"].astype(np.float64), state_list_from(config, res["state"])
+
+
+def state_list_from(config, state):
+    """int32 state codes -> the package's ``state_list`` (label symbol, "ε" or "")."""
+    chars = config.char_list
+    out = []
+    for s in np.asarray(state).tolist():
+        if s == -2:
+            out.append("")
+        elif s == -1:
+            out.append(config.self_transition)
+        else:
+            out.append(chars[s] if chars is not None else s)
+    return out

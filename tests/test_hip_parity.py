@@ -1,0 +1,218 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on seeded inputs.
+
+Bar (BASELINE.json north_star): frame indices bit-exact, confidence scores within 1e-4.
+char_prob values are fp32 emissions copied out, so they are compared exactly too.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-4  # the tolerance north_star states for log-prob confidence scores
+DUR = 320.4769 / 16000
+
+
+def _check(pkg, oracle, segs, res, cfg_kw=None):
+    ocfg = oracle.make_config(index_duration=DUR, **(cfg_kw or {}))
+    for i, ((lpz, gt, ub), r) in enumerate(zip(segs, res)):
+        o = oracle.get_segments(lpz, gt, ub, ocfg)
+        assert r["status"] == o["status"], (i, r["status"], o["status"])
+        if o["status"] != 0:
+            continue
+        assert r["t_end"] == o["t_end"], i
+        assert np.array_equal(r["frame_of_label"], o["frame_of_label"]), f"segment {i}: frame indices differ"
+        assert np.array_equal(r["char_prob"].astype(np.float64), o["char_probs"]), f"segment {i}: char_probs"
+        assert np.array_equal(r["state"], o["state"]), f"segment {i}: state list"
+        assert np.array_equal(r["seg_start"], o["seg_start"]), i
+        assert np.array_equal(r["seg_end"], o["seg_end"]), i
+        np.testing.assert_allclose(r["seg_score"], o["seg_score"], rtol=0, atol=SCORE_TOL)
+
+
+def _run(pkg, segs, **cfg):
+    config = pkg.CtcSegmentationParameters(index_duration=DUR, **cfg)
+    return pkg.ctc_segmentation.get_segments_device(config, [s[0] for s in segs], [s[1] for s in segs],
+                                                    [s[2] for s in segs])
+
+
+def test_ragged_batch_matches_oracle(pkg, oracle):
+    syn = pkg.synthetic
+    rng = np.random.default_rng(7)
+    segs = []
+    for seed in range(24):
+        T = int(rng.integers(40, 900))
+        U = int(rng.integers(1, 6))
+        n = int(rng.integers(3, max(4, min(30, (T - 3) // (U + 1)))))
+        segs.append(syn.make_segment(seed, T, 32, U, n))
+    _check(pkg, oracle, segs, _run(pkg, segs))
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 8, 10, 12, 16])
+def test_every_lane_tile_width(pkg, oracle, engine, K):
+    """Force each compiled cols-per-lane variant through the plan API (device buffers)."""
+    import torch
+
+    syn = pkg.synthetic
+    segs = [syn.make_segment(100 + s, T, 32, U, n) for s, (T, U, n) in
+            enumerate([(600, 5, 25), (333, 3, 17), (1000, 9, 30), (97, 1, 40)])]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    T = [s[0].shape[0] for s in segs]
+    C = [len(s[1]) for s in segs]
+    U = [len(s[2]) - 1 for s in segs]
+    plan = engine.plan(config.to_native(), 32, T, C, U, force_cols_per_lane=K)
+    assert plan.info["cols_per_lane"] == K
+    dev = torch.device("cuda:0")
+    d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in segs])).to(dev)
+    d_lab = torch.from_numpy(np.concatenate([s[1] for s in segs]).astype(np.int32)).to(dev)
+    d_ub = torch.from_numpy(np.concatenate([s[2] for s in segs]).astype(np.int32)).to(dev)
+    nT, nC, nU = sum(T), sum(C), sum(U)
+    d_fol = torch.empty(nC, dtype=torch.int32, device=dev)
+    d_cp = torch.empty(nT, dtype=torch.float32, device=dev)
+    d_st = torch.empty(nT, dtype=torch.int32, device=dev)
+    d_seg = torch.empty(3, nU, dtype=torch.float64, device=dev)
+    d_te = torch.empty(len(segs), dtype=torch.int32, device=dev)
+    d_status = torch.empty(len(segs), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), d_fol.data_ptr(), d_cp.data_ptr(),
+                    d_st.data_ptr(), d_seg[0].data_ptr(), d_seg[1].data_ptr(), d_seg[2].data_ptr(),
+                    d_te.data_ptr(), d_status.data_ptr(), stream)
+    torch.cuda.synchronize()
+    fol, cp, st = d_fol.cpu().numpy(), d_cp.cpu().numpy(), d_st.cpu().numpy()
+    seg, te, status = d_seg.cpu().numpy(), d_te.cpu().numpy(), d_status.cpu().numpy()
+    res = []
+    to = np.concatenate([[0], np.cumsum(T)])
+    co = np.concatenate([[0], np.cumsum(C)])
+    uo = np.concatenate([[0], np.cumsum(U)])
+    for b in range(len(segs)):
+        res.append(dict(status=int(status[b]), t_end=int(te[b]), frame_of_label=fol[co[b]:co[b + 1]],
+                        char_prob=cp[to[b]:to[b + 1]], state=st[to[b]:to[b + 1]],
+                        seg_start=seg[0][uo[b]:uo[b + 1]], seg_end=seg[1][uo[b]:uo[b + 1]],
+                        seg_score=seg[2][uo[b]:uo[b + 1]]))
+    _check(pkg, oracle, segs, res)
+    plan.close()
+
+
+@pytest.mark.parametrize("V", [5, 29, 32, 40, 64, 100, 128])
+def test_vocabulary_sizes(pkg, oracle, V):
+    syn = pkg.synthetic
+    segs = [syn.make_segment(200 + s + V, T, V, U, n) for s, (T, U, n) in
+            enumerate([(400, 4, 20), (250, 2, 31), (64, 1, 10)])]
+    _check(pkg, oracle, segs, _run(pkg, segs))
+
+
+def test_nonzero_blank_index(pkg, oracle):
+    syn = pkg.synthetic
+    segs = [syn.make_segment(300 + s, 300, 32, 3, 20, blank=31) for s in range(4)]
+    _check(pkg, oracle, segs, _run(pkg, segs, blank=31), dict(blank=31))
+
+
+def test_audio_shorter_than_text_status_and_exception(pkg, oracle):
+    syn = pkg.synthetic
+    short = syn.make_segment(1, 30, 32, 2, 20)   # C = 44 > T = 30
+    ok = syn.make_segment(2, 200, 32, 2, 20)
+    res = _run(pkg, [short, ok, short])
+    assert [r["status"] for r in res] == [1, 0, 1]
+    _check(pkg, oracle, [short, ok, short], res)
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    with pytest.raises(AssertionError, match="Audio is shorter than text!"):
+        pkg.ctc_segmentation.ctc_segmentation(config, short[0], short[1].reshape(-1, 1))
+
+
+def test_forced_diagonal_T_equals_C(pkg, oracle):
+    """T == C leaves exactly one path: every frame switches (known answer)."""
+    syn = pkg.synthetic
+    lpz, gt, ub = syn.make_segment(5, 62, 32, 2, 29)  # C = 1 + 2*30 + 1 = 62
+    assert len(gt) == 62
+    res = _run(pkg, [(lpz, gt, ub)])
+    assert res[0]["status"] == 0
+    assert np.array_equal(res[0]["frame_of_label"], np.arange(62))
+    _check(pkg, oracle, [(lpz, gt, ub)], res)
+
+
+def test_one_hot_emissions_unique_path(pkg, oracle):
+    """Near one-hot emissions along a planted path: the alignment must recover it."""
+    rng = np.random.default_rng(11)
+    V, T = 32, 500
+    gt, ub = pkg.synthetic.make_labels(rng, 4, 20, V)
+    C = len(gt)
+    firsts = np.sort(rng.choice(np.arange(1, T), size=C - 1, replace=False))
+    logits = np.full((T, V), -30.0, np.float32)
+    col = np.zeros(T, np.int64)
+    col[firsts] = 1
+    col = np.cumsum(col)
+    logits[np.arange(T), 0] = 0.0           # blank everywhere ...
+    logits[firsts, :] = -30.0
+    logits[firsts, gt[1:]] = 0.0            # ... except the first frame of each label
+    lpz = (logits - np.log(np.exp(logits.astype(np.float64)).sum(1, keepdims=True))).astype(np.float32)
+    res = _run(pkg, [(lpz, gt, ub)])
+    assert res[0]["status"] == 0
+    assert np.array_equal(res[0]["frame_of_label"][1:], firsts)
+    _check(pkg, oracle, [(lpz, gt, ub)], res)
+
+
+def test_backtrack_from_max_t(pkg, oracle):
+    syn = pkg.synthetic
+    segs = [syn.make_segment(400 + s, 350, 32, 3, 22) for s in range(3)]
+    _check(pkg, oracle, segs, _run(pkg, segs, backtrack_from_max_t=True), dict(backtrack_from_max_t=1))
+
+
+def test_preamble_cost_not_zero(pkg, oracle):
+    syn = pkg.synthetic
+    segs = [syn.make_segment(500 + s, 280, 32, 3, 18) for s in range(3)]
+    _check(pkg, oracle, segs, _run(pkg, segs, preamble_transition_cost_zero=False),
+           dict(preamble_transition_cost_zero=0))
+
+
+def test_scoring_lengths(pkg, oracle):
+    syn = pkg.synthetic
+    segs = [syn.make_segment(600 + s, 500, 32, 4, 25) for s in range(2)]
+    for L in (1, 7, 8, 30, 64, 128):
+        _check(pkg, oracle, segs, _run(pkg, segs, score_min_mean_over_L=L), dict(score_min_mean_over_L=L))
+
+
+def test_longer_segments_full_size_column_count(pkg, oracle):
+    """T = 3000, C = 640 (BASELINE.json configs[2] geometry), a handful of segments."""
+    syn = pkg.synthetic
+    segs = [syn.make_segment(700 + s, 3000, 32, 22, 28) for s in range(6)]
+    _check(pkg, oracle, segs, _run(pkg, segs))
+
+
+def test_sharp_emissions_use_all_frames(pkg, oracle):
+    """Strong planted peaks: the best path runs to the last frames (long backtrack)."""
+    segs = []
+    for s in range(4):
+        gt, ub = pkg.synthetic.make_labels(np.random.default_rng(900 + s), 10, 24, 32)
+        lpz = pkg.synthetic.make_emissions(np.random.default_rng(800 + s), 1500, 32, gt, noise=1.0, peak=14.0)
+        segs.append((lpz, gt, ub))
+    res = _run(pkg, segs)
+    assert all(r["t_end"] > 1300 for r in res)
+    _check(pkg, oracle, segs, res)
+
+
+def test_speechbrain_protocol_str_task(pkg, oracle):
+    """get_lpz -> prepare_segmentation_task -> get_segments -> task.set -> str(task),
+    the exact call sequence of iterative_utterance_alignment.py:201-219."""
+    from tests.fakes import FakeASR
+
+    asr = FakeASR(seed=3)
+    aligner = pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed", scoring_length=30)
+    ratio = aligner.estimate_samples_to_frames_ratio()
+    assert abs(ratio - 320.0) < 1.0
+    import torch
+    audio = torch.from_numpy(np.random.default_rng(0).standard_normal(16000 * 6).astype(np.float32))
+    lpz = aligner.get_lpz(audio)
+    text = ["HOLA QUE TAL", "MUY BIEN GRACIAS", "ADIOS"]
+    task = aligner.prepare_segmentation_task(text, lpz, "utt_7", audio.shape[0])
+    segments = aligner.get_segments(task)
+    task.set(**segments)
+    lines = str(task).strip().split("\n")
+    assert len(lines) == 3
+    fields = [ln.split(" ", 5) for ln in lines]
+    assert all(len(f) == 6 for f in fields)
+    assert [f[0] for f in fields] == ["utt_7_0000", "utt_7_0001", "utt_7_0002"]
+    assert [f[5] for f in fields] == text
+    # against the oracle on the same label matrix
+    ocfg = oracle.make_config(index_duration=aligner.config.index_duration)
+    o = oracle.get_segments(lpz, task.ground_truth_mat[:, 0], task.utt_begin_indices, ocfg)
+    for f, s, e, sc in zip(fields, o["seg_start"], o["seg_end"], o["seg_score"]):
+        assert f[2] == f"{s:.2f}" and f[3] == f"{e:.2f}"
+        assert abs(float(f[4]) - sc) <= SCORE_TOL + 5e-5
