@@ -83,7 +83,7 @@ FillFn fill_for_k(int K) {
 int ept_for(int VP, int W) {
     const int nst_max = 64 * (W >= 4 ? 4 : (W >= 2 ? 2 : 1));
     const int ept = ctcfa::kRows * VP / nst_max;
-    return ept < 4 ? 4 : ept;  // 4, 8 or 16; > 16 means the shape is not allowed
+    return ept < 4 ? 4 : ept;  // 4, 8, 16 (or 32 for the 128-entry pitch); larger = not allowed
 }
 
 FillFn select_fill(int K, int VP, int EPT) {
@@ -94,6 +94,7 @@ FillFn select_fill(int K, int VP, int EPT) {
         case 6408: return fill_for_k<64, 8>(K);
         case 6416: return fill_for_k<64, 16>(K);
         case 12816: return fill_for_k<128, 16>(K);
+        case 12832: return fill_for_k<128, 32>(K);
         default: return nullptr;
     }
 }
@@ -101,7 +102,7 @@ FillFn select_fill(int K, int VP, int EPT) {
 const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
 
 int lds_bytes_fill(int W, int VP) {
-    return (W + 1) * ctcfa::kRows * (VP + 1) * 8 + (W + 1) * ctcfa::kBnd * 4;
+    return (W + 1) * ctcfa::kRows * (VP + 1) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + (ctcfa::kRows + 96) * 4;
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
@@ -116,9 +117,12 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int force_k, int* K_out,
     for (int K : kKs) {
         if (force_k && K != force_k) continue;
         const int padded = roundup(Cmax, K);
-        const int W = (padded + 64 * K - 1) / (64 * K);
+        int W = (padded + 64 * K - 1) / (64 * K);
+        // a wide vocabulary needs enough staging threads (EPT <= 16): idle waves own padding only
+        const int Wmin = VP <= 32 ? 1 : 2;
+        if (W < Wmin) W = Wmin;
         if (W > 16 || (K >= 10 && W > 4)) continue;  // K >= 10 kernels are built for <= 256 threads
-        if (ept_for(VP, W) > 16) continue;           // too few waves to stage a wide vocabulary
+        if (ept_for(VP, W) > (VP == 128 ? 32 : 16)) continue;  // too few waves to stage a wide vocabulary
         if (lds_bytes_fill(W, VP) > lds_limit) continue;
         const double fill = (double)Cmax / (64.0 * K * W);           // useful lanes
         const double amort = (9.0 * K) / (9.0 * K + 5.0);             // per-row fixed cost

@@ -31,6 +31,7 @@ namespace ctcfa {
 
 constexpr int kRows = 32;      // rows per block == bits per decision word
 constexpr int kBnd = 128;      // ring length (rows) of the cross-wave boundary column
+constexpr int kBndPitch = 132; // + mirror entry, padded to 16 B
 constexpr float kProbMax = -1000000000.0f;   // Cython sentinel (prob_max)
 constexpr float kMaxProb = -10000000000.0f;  // config.max_prob on the NumPy side
 
@@ -89,7 +90,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
 
-    float* bnd = reinterpret_cast<float*>(smem + NS * SLOT_BYTES);  // [(W+1)][kBnd]
+    // LDS after the emission ring:
+    //   bnd   [(W+1)][kBndPitch] floats  boundary columns, physical index p holds row t with
+    //                                    (t-1) % 128 == p-1; p == 0 mirrors p == 128
+    //   lcbuf [32] floats                last label column of the current block (owner wave)
+    //   dummy [96] floats                sink for the lanes that publish nothing
+    const uint32_t bnd_base = static_cast<uint32_t>(NS * SLOT_BYTES);
+    const uint32_t lcbuf_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
+    const uint32_t dummy_base = lcbuf_base + kRows * 4;
+    float* bnd = reinterpret_cast<float*>(smem + bnd_base);
     const int nblk = (T - 1 + kRows - 1) / kRows;
     const int Cpad = 64 * K * W;
     const int nsteps = nblk + W - 1;
@@ -111,9 +120,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         dec[k] = 0u;
     }
     const int pcl = C - 1 + shift;  // padded index of the last label column
-    const bool owns_last = (w == pcl / (64 * K)) && (lane == (pcl % (64 * K)) / K);
+    const int wstar = pcl / (64 * K);
+    const bool owns_last = (w == wstar) && (lane == (pcl % (64 * K)) / K);
 
-    for (int i = tid; i < (W + 1) * kBnd; i += nthreads) bnd[i] = kProbMax;
+    const int lstar = (pcl % (64 * K)) / K;
+    for (int i = tid; i < (W + 1) * kBndPitch; i += nthreads) bnd[i] = kProbMax;
 
     // ---- staging: global -> registers -> (e, m) pairs in LDS ----------------------------
     const bool stager = tid < NST;  // wave-uniform
@@ -174,19 +185,34 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             cur_slot = slot;
 #pragma unroll
             for (int k = 0; k < K; ++k) gaddr[k] += delta;
-            const int tb = j * kRows + 1;
-            const float* bnd_in = bnd + w * kBnd;
-            float* bnd_out = bnd + (w + 1) * kBnd;
+            const int q = j & 3;
+            // consumer side: row i of this block needs row t-1 -> physical q*32 + i of ring w
+            const uint32_t in_addr = bnd_base + static_cast<uint32_t>((w * kBndPitch + q * kRows) * 4);
+            // producer side: lane 63 publishes row i at physical q*32 + 1 + i of ring w+1; the
+            // owner of the last label column also keeps it in lcbuf; every other lane writes
+            // to a sink, so the row loop has one unpredicated ds_write with an immediate offset
+            uint32_t out_addr = dummy_base + static_cast<uint32_t>(lane * 4);
+            if (owns_last) out_addr = lcbuf_base;
+            if (lane == 63) out_addr = bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows + 1) * 4);
 
-#pragma unroll 2
+            float2 em_next[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) em_next[k] = *reinterpret_cast<const float2*>(smem + gaddr[k]);
+            float lin_next = *reinterpret_cast<const float*>(smem + in_addr);
+
+#pragma unroll
             for (int i = 0; i < kRows; ++i) {
-                const int t = tb + i;
-                const float lin = (w == 0) ? 0.0f : bnd_in[(t - 1) & (kBnd - 1)];
-                const float leftv = dpp_wave_shr1(lin, prev[K - 1]);
                 float2 em[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k)
-                    em[k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + i * (PITCH * 8));
+                for (int k = 0; k < K; ++k) em[k] = em_next[k];
+                const float lin = lin_next;
+                if (i + 1 < kRows) {  // software prefetch of the next row's operands
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        em_next[k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + 1) * (PITCH * 8));
+                    lin_next = *reinterpret_cast<const float*>(smem + in_addr + (i + 1) * 4);
+                }
+                const float leftv = dpp_wave_shr1(lin, prev[K - 1]);
 #pragma unroll
                 for (int k = K - 1; k >= 0; --k) {
                     const float pl = (k == 0) ? leftv : prev[k > 0 ? k - 1 : 0];
@@ -201,12 +227,22 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
                     prev[k] = nw;
                 }
-                if (lane == 63) bnd_out[t & (kBnd - 1)] = prev[K - 1];
-                if (owns_last && t < T) seg_lastcol[t] = prev[K - 1];
+                *reinterpret_cast<float*>(smem + out_addr + i * 4) = prev[K - 1];
             }
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + (w * 64 + lane) * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) bp[k] = dec[k];
+            if (q == 3 && lane == 63)  // mirror: physical 0 of the ring == physical 128
+                bnd[(w + 1) * kBndPitch] = prev[K - 1];
+            if (w == wstar) {  // flush this block's last-column scores (argmax of the end cell)
+                const int t = j * kRows + 1 + lane;
+                if (lane < kRows && t < T) {
+                    const uint32_t src = (lstar == 63)
+                        ? bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows + 1 + lane) * 4)
+                        : lcbuf_base + static_cast<uint32_t>(lane * 4);
+                    seg_lastcol[t] = *reinterpret_cast<const float*>(smem + src);
+                }
+            }
         }
 
         if (have_next) stage_write(s + 1);
@@ -323,15 +359,23 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
         int j = (t_end - 1) >> 5;
         int b0 = 31 - ((t_end - 1) & 31);
         const uint32_t* seg_bits = bits + sd.bits_off;
+        // lane i holds the decision word of column (base - i) for the block being walked;
+        // the next block's 64 candidate columns are fetched before the walk starts, so the
+        // HBM/L2 latency of one block overlaps the walk of the previous one.
+        auto fetch = [&](int jb, int base) -> uint32_t {
+            const int col = base - lane;
+            return (jb >= 0 && col >= 0) ? seg_bits[(int64_t)jb * p.Cpad + col] : 0u;
+        };
+        int base = pc;
+        uint32_t wl = fetch(j, base);
         while (j >= 0) {
             const int cstart = pc;
+            const int next_base = pc;
+            const uint32_t wl_next = fetch(j - 1, next_base);
             uint32_t S = 0;
             if (pc - shift > 0) {
-                const int col = pc - lane;
-                uint32_t wl = 0;
-                if (lane < 32 && col >= 0) wl = seg_bits[(int64_t)j * p.Cpad + col];
                 for (;;) {
-                    uint32_t wv = __builtin_amdgcn_readlane(wl, cstart - pc);
+                    uint32_t wv = __builtin_amdgcn_readlane(wl, base - pc);
                     if (pc - shift <= 0) wv = 0;  // start column: always STAY
                     const uint32_t m = (b0 < 32) ? (wv & (0xffffffffu << b0)) : 0u;
                     if (m == 0) break;
@@ -345,6 +389,8 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             if (lane == 0) rec[j] = make_int2(cstart, (int)S);
             --j;
             b0 = 0;
+            wl = wl_next;
+            base = next_base;
         }
         if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
     } else {
