@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--cols-per-lane", type=int, default=int(os.environ.get("CTCFA_K", "0")))
     ap.add_argument("--cpu-sample", type=int, default=256, help="segments timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of segment boundaries")
+    ap.add_argument("--no-check", action="store_true",
+                    help="kernel-tuning only: skip the status/parity gate (ablated builds give wrong results)")
     return ap.parse_args()
 
 
@@ -123,9 +125,9 @@ def main():
 
     # ---- parity gate on the timed inputs (a sample; the full sweep is tests/ -m gpu) -------
     status = d_status.cpu().numpy()
-    assert (status == 0).all(), "non-OK status in the benchmark batch"
+    assert args.no_check or (status == 0).all(), "non-OK status in the benchmark batch"
     parity = None
-    if rank == 0:
+    if rank == 0 and not args.no_check:
         from oracle import oracle_c
         ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
         fol = d_fol.cpu().numpy().reshape(B, C)

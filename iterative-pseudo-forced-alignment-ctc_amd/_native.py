@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libctcfa_hip.so")
+# CTCFA_LIB: alternative build of the same library (kernel-tuning experiments only)
+LIB_PATH = os.environ.get("CTCFA_LIB") or os.path.join(_HERE, "csrc", "libctcfa_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, 1, 2, 3, 4
 ST_OK, ST_AUDIO_SHORTER_THAN_TEXT, ST_BACKTRACK_FAILED, ST_WINDOWED_UNSUPPORTED = 0, 1, 2, 3

@@ -62,39 +62,28 @@ int set_err(ctcfa_engine* e, int code, const std::string& msg) {
 
 using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int);
 
-template <int VP, int EPT>
+template <int VP>
 FillFn fill_for_k(int K) {
     switch (K) {
-        case 1: return ctcfa::fill_kernel<1, VP, EPT>;
-        case 2: return ctcfa::fill_kernel<2, VP, EPT>;
-        case 3: return ctcfa::fill_kernel<3, VP, EPT>;
-        case 4: return ctcfa::fill_kernel<4, VP, EPT>;
-        case 5: return ctcfa::fill_kernel<5, VP, EPT>;
-        case 6: return ctcfa::fill_kernel<6, VP, EPT>;
-        case 8: return ctcfa::fill_kernel<8, VP, EPT>;
-        case 10: return ctcfa::fill_kernel<10, VP, EPT>;
-        case 12: return ctcfa::fill_kernel<12, VP, EPT>;
-        case 16: return ctcfa::fill_kernel<16, VP, EPT>;
+        case 1: return ctcfa::fill_kernel<1, VP>;
+        case 2: return ctcfa::fill_kernel<2, VP>;
+        case 3: return ctcfa::fill_kernel<3, VP>;
+        case 4: return ctcfa::fill_kernel<4, VP>;
+        case 5: return ctcfa::fill_kernel<5, VP>;
+        case 6: return ctcfa::fill_kernel<6, VP>;
+        case 8: return ctcfa::fill_kernel<8, VP>;
+        case 10: return ctcfa::fill_kernel<10, VP>;
+        case 12: return ctcfa::fill_kernel<12, VP>;
+        case 16: return ctcfa::fill_kernel<16, VP>;
         default: return nullptr;
     }
 }
 
-// Staging shape: the first NST = 32*VP/EPT threads stage; NST <= 64*W must hold.
-int ept_for(int VP, int W) {
-    const int nst_max = 64 * (W >= 4 ? 4 : (W >= 2 ? 2 : 1));
-    const int ept = ctcfa::kRows * VP / nst_max;
-    return ept < 4 ? 4 : ept;  // 4, 8, 16 (or 32 for the 128-entry pitch); larger = not allowed
-}
-
-FillFn select_fill(int K, int VP, int EPT) {
-    switch (VP * 100 + EPT) {
-        case 3204: return fill_for_k<32, 4>(K);
-        case 3208: return fill_for_k<32, 8>(K);
-        case 3216: return fill_for_k<32, 16>(K);
-        case 6408: return fill_for_k<64, 8>(K);
-        case 6416: return fill_for_k<64, 16>(K);
-        case 12816: return fill_for_k<128, 16>(K);
-        case 12832: return fill_for_k<128, 32>(K);
+FillFn select_fill(int K, int VP) {
+    switch (VP) {
+        case 32: return fill_for_k<32>(K);
+        case 64: return fill_for_k<64>(K);
+        case 128: return fill_for_k<128>(K);
         default: return nullptr;
     }
 }
@@ -102,7 +91,8 @@ FillFn select_fill(int K, int VP, int EPT) {
 const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
 
 int lds_bytes_fill(int W, int VP) {
-    return (W + 1) * ctcfa::kRows * (VP + 1) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + (ctcfa::kRows + 96) * 4;
+    // emission ring (W+1 slots) + boundary columns + last-column buffer + publish sink
+    return (W + 1) * ctcfa::kRows * (VP + 1) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + ctcfa::kRows * 4 + 96 * 4;
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
@@ -117,12 +107,8 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int force_k, int* K_out,
     for (int K : kKs) {
         if (force_k && K != force_k) continue;
         const int padded = roundup(Cmax, K);
-        int W = (padded + 64 * K - 1) / (64 * K);
-        // a wide vocabulary needs enough staging threads (EPT <= 16): idle waves own padding only
-        const int Wmin = VP <= 32 ? 1 : 2;
-        if (W < Wmin) W = Wmin;
-        if (W > 16 || (K >= 10 && W > 4)) continue;  // K >= 10 kernels are built for <= 256 threads
-        if (ept_for(VP, W) > (VP == 128 ? 32 : 16)) continue;  // too few waves to stage a wide vocabulary
+        const int W = (padded + 64 * K - 1) / (64 * K);
+        if (W > 15 || (K >= 10 && W > 4)) continue;  // +1 producer wave; K >= 10 kernels: <= 320 threads
         if (lds_bytes_fill(W, VP) > lds_limit) continue;
         const double fill = (double)Cmax / (64.0 * K * W);           // useful lanes
         const double amort = (9.0 * K) / (9.0 * K + 5.0);             // per-row fixed cost
@@ -249,7 +235,7 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }
-    pl->fill_fn = select_fill(pl->K, pl->VP, ept_for(pl->VP, pl->W));
+    pl->fill_fn = select_fill(pl->K, pl->VP);
     if (!pl->fill_fn) {
         delete pl;
         return set_err(eng, CTCFA_ERR_INVALID, "unsupported cols_per_lane");
@@ -358,8 +344,9 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
 
     hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 3] : nullptr;
     if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->W), pl->lds_fill, st, pl->d_segs, d_lpz,
-                       d_labels, pl->d_bits, pl->d_lastcol, pl->V, pl->prm.blank,
+    float* lastcol_arg = pl->d_lastcol;
+    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * (pl->W + 1)), pl->lds_fill, st, pl->d_segs, d_lpz,
+                       d_labels, pl->d_bits, lastcol_arg, pl->V, pl->prm.blank,
                        (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0);
     HIP_TRY(eng, hipGetLastError());
     if (ev) HIP_TRY(eng, hipEventRecord(ev[1], st));

@@ -25,6 +25,9 @@
 //     4*T*V (emissions, once) + T*Cpad/8 (bits) + 4*T (last-column scores).
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef CTCFA_PF
+#define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
+#endif
 #include <stdint.h>
 
 namespace ctcfa {
@@ -53,35 +56,41 @@ __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) {
                                                       __float_as_int(src), 0x138, 0xf, 0xf, false));
 }
 
+__device__ __forceinline__ void lds_barrier() {
+    // workgroup barrier that orders LDS traffic only: lowers to s_waitcnt lgkmcnt(0) +
+    // s_barrier, with no vmcnt drain for global stores that nobody in this kernel reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
 // ---------------------------------------------------------------------------------------
-// Fill kernel.  grid = B workgroups, block = 64*W threads, dynamic LDS =
-//   (W+1) * kRows * (VP+1) * 8   (emission ring)  +  (W+1) * kBnd * 4  (boundary columns)
+// Fill kernel.  grid = B workgroups (one per segment), block = 64*(W+1) threads:
+//   waves 0..W-1  compute waves, wave w owns padded columns [w*64K, (w+1)*64K)
+//   wave  W       producer: stages emission rows global -> (e, m) pairs in the LDS ring
+// Roles never mix: compute waves issue only global STORES (decision words, last-column
+// scores) and never wait on vmcnt; the producer issues only LOADS.  (vmcnt retires in issue
+// order on gfx9, so one wave doing both pays an HBM write round trip in every load wait.)
+// dynamic LDS = (W+1) slots * kRows * (VP+1) * 8  +  boundary columns  +  small buffers.
 // ---------------------------------------------------------------------------------------
-// EPT = staged elements per staging thread per block (4, 8 or 16): the first
-// NST = kRows*VP/EPT threads of the workgroup stage, each exactly EPT rows of one
-// vocabulary entry, so the prefetch registers are a fixed-size array with no predication.
-template <int K, int VP, int EPT>
-__global__ void __launch_bounds__((K >= 10) ? 256 : 1024)
+template <int K, int VP>
+__global__ void __launch_bounds__((K >= 10) ? 320 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int preamble) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int PITCH = VP + 1;
     constexpr int SLOT_BYTES = kRows * PITCH * 8;
-    constexpr int NST = kRows * VP / EPT;  // staging threads (multiple of 64 and of VP)
-    constexpr int RSTEP = NST / VP;        // row stride of one staging thread
-    static_assert(NST % 64 == 0 && NST % VP == 0 && RSTEP * EPT == kRows, "staging shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = blockDim.x >> 6;
-    const int nthreads = blockDim.x;
-    const int NS = W + 1;
+    const int W = (blockDim.x >> 6) - 1;  // compute waves
+    const int NS = W + 1;                 // ring slots: W blocks being read + 1 being written
 
     const SegDesc sd = segs[blockIdx.x];
     if (sd.prestatus != 0) return;  // uniform: nothing to fill
@@ -91,19 +100,78 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
 
     // LDS after the emission ring:
-    //   bnd   [(W+1)][kBndPitch] floats  boundary columns, physical index p holds row t with
-    //                                    (t-1) % 128 == p-1; p == 0 mirrors p == 128
+    //   bnd   [(W+1)][kBndPitch] floats  boundary columns; physical index p holds row t with
+    //                                    (t-1) % 128 == p-1, p == 0 mirrors p == 128
     //   lcbuf [32] floats                last label column of the current block (owner wave)
-    //   dummy [96] floats                sink for the lanes that publish nothing
+    //   sink  [96] floats                target of the lanes that publish nothing
     const uint32_t bnd_base = static_cast<uint32_t>(NS * SLOT_BYTES);
     const uint32_t lcbuf_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
-    const uint32_t dummy_base = lcbuf_base + kRows * 4;
+    const uint32_t sink_base = lcbuf_base + kRows * 4;
     float* bnd = reinterpret_cast<float*>(smem + bnd_base);
     const int nblk = (T - 1 + kRows - 1) / kRows;
     const int Cpad = 64 * K * W;
     const int nsteps = nblk + W - 1;
 
-    // ---- per-lane column setup ----------------------------------------------------------
+    for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = kProbMax;
+
+    if (w == W) {
+        // ============================ producer wave ===========================================
+        // Block jb = rows t in [32*jb + 1, 32*jb + 32].  Per pass the wave covers 64/VP rows
+        // (VP <= 64) or half a row (VP == 128); CH loads are in flight before the first use.
+        constexpr int PASSES = kRows * VP / 64;
+        constexpr int CH = PASSES < 16 ? PASSES : 16;
+        const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
+        auto stage_block = [&](int jb) {
+            unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
+            const int t0 = jb * kRows + 1;
+#pragma unroll 1
+            for (int p0 = 0; p0 < PASSES; p0 += CH) {
+                float e[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int idx = (p0 + q) * 64 + lane;  // element of the block
+                    const int sv = idx % VP;               // vocabulary entry (lane-invariant for VP <= 64)
+                    const int svc = sv < V ? sv : V - 1;
+                    int t = t0 + idx / VP;
+                    t = t < T ? t : T - 1;                 // rows past the end: re-read, discarded below
+                    e[q] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V + svc) * 4u);
+                }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int idx = (p0 + q) * 64 + lane;
+                    const int sv = idx % VP;
+                    const int r = idx / VP;
+                    const int t = t0 + r;
+                    float lb;
+                    if constexpr (VP == 32) {  // two rows per pass: the row's blank entry via readlane
+                        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
+                        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), 32 + blank));
+                        lb = (lane < 32) ? lo : hi;
+                    } else if constexpr (VP == 64) {
+                        lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
+                    } else {
+                        const int tc = t < T ? t : T - 1;
+                        lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
+                    }
+                    const bool valid = t < T;
+                    float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
+                    if (sv < V) row[sv] = valid ? make_float2(e[q], max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
+                    if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
+                        row[VP] = make_float2(-__builtin_inff(),
+                                              (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                }
+            }
+        };
+        stage_block(0);
+        lds_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nblk) stage_block(s + 1);  // slot (s+1) % NS was last read in step s-1
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ================================ compute waves ===========================================
     float prev[K];
     uint32_t dec[K];
     uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair in row 0 of the current slot
@@ -121,63 +189,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     }
     const int pcl = C - 1 + shift;  // padded index of the last label column
     const int wstar = pcl / (64 * K);
-    const bool owns_last = (w == wstar) && (lane == (pcl % (64 * K)) / K);
-
     const int lstar = (pcl % (64 * K)) / K;
-    for (int i = tid; i < (W + 1) * kBndPitch; i += nthreads) bnd[i] = kProbMax;
+    const bool owns_last = (w == wstar) && (lane == lstar);
 
-    // ---- staging: global -> registers -> (e, m) pairs in LDS ----------------------------
-    const bool stager = tid < NST;  // wave-uniform
-    const int sv = tid % VP;
-    const int r0 = tid / VP;
-    const int svc = sv < V ? sv : V - 1;
-    const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
-    float stg[EPT];
-    auto stage_load = [&](int jb) {
-        if (!stager) return;
-        const int t0 = jb * kRows + 1 + r0;
-#pragma unroll
-        for (int it = 0; it < EPT; ++it) {
-            int t = t0 + it * RSTEP;
-            t = t < T ? t : T - 1;  // rows past the end re-read the last row (discarded below)
-            const uint32_t off = static_cast<uint32_t>(t * V + svc) * 4u;
-            stg[it] = *reinterpret_cast<const float*>(lpz_bytes + off);
-        }
-    };
-    auto stage_write = [&](int jb) {
-        if (!stager) return;
-        unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
-        const int t0 = jb * kRows + 1 + r0;
-#pragma unroll
-        for (int it = 0; it < EPT; ++it) {
-            const int r = r0 + it * RSTEP;
-            const int t = t0 + it * RSTEP;
-            const float e = stg[it];
-            float lb;
-            if constexpr (VP <= 64) {
-                lb = __shfl(e, (lane & ~(VP - 1)) + blank);  // the row's blank entry sits in this wave
-            } else {
-                const int tc = t < T ? t : T - 1;
-                lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
-            }
-            const bool valid = t < T;
-            float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
-            if (sv < V) row[sv] = valid ? make_float2(e, max3f(lb, e, kProbMax)) : make_float2(0.f, 0.f);
-            if (sv == 0)
-                row[VP] = make_float2(-__builtin_inff(),
-                                      (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-        }
-    };
-
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
+    lds_barrier();  // block 0 staged, boundary columns initialised
 
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
     for (int s = 0; s < nsteps; ++s) {
-        const bool have_next = (s + 1 < nblk);
-        if (have_next) stage_load(s + 1);
-
         const int j = s - w;
         if (j >= 0 && j < nblk) {
             const int slot = j % NS;
@@ -191,26 +209,33 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // producer side: lane 63 publishes row i at physical q*32 + 1 + i of ring w+1; the
             // owner of the last label column also keeps it in lcbuf; every other lane writes
             // to a sink, so the row loop has one unpredicated ds_write with an immediate offset
-            uint32_t out_addr = dummy_base + static_cast<uint32_t>(lane * 4);
+            uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 4);
             if (owns_last) out_addr = lcbuf_base;
             if (lane == 63) out_addr = bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows + 1) * 4);
 
-            float2 em_next[K];
+            // software pipeline: operands of row i+PF are requested while row i is computed
+            constexpr int PF = CTCFA_PF;
+            float2 emq[PF][K];
+            float linq[PF];
 #pragma unroll
-            for (int k = 0; k < K; ++k) em_next[k] = *reinterpret_cast<const float2*>(smem + gaddr[k]);
-            float lin_next = *reinterpret_cast<const float*>(smem + in_addr);
+            for (int d = 0; d < PF; ++d) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * (PITCH * 8));
+                linq[d] = *reinterpret_cast<const float*>(smem + in_addr + d * 4);
+            }
 
 #pragma unroll
             for (int i = 0; i < kRows; ++i) {
                 float2 em[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) em[k] = em_next[k];
-                const float lin = lin_next;
-                if (i + 1 < kRows) {  // software prefetch of the next row's operands
+                for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
+                const float lin = linq[i % PF];
+                if (i + PF < kRows) {
 #pragma unroll
                     for (int k = 0; k < K; ++k)
-                        em_next[k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + 1) * (PITCH * 8));
-                    lin_next = *reinterpret_cast<const float*>(smem + in_addr + (i + 1) * 4);
+                        emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * (PITCH * 8));
+                    linq[i % PF] = *reinterpret_cast<const float*>(smem + in_addr + (i + PF) * 4);
                 }
                 const float leftv = dpp_wave_shr1(lin, prev[K - 1]);
 #pragma unroll
@@ -229,6 +254,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
                 *reinterpret_cast<float*>(smem + out_addr + i * 4) = prev[K - 1];
             }
+            // decision words of this block (fire and forget: this wave never waits on vmcnt)
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + (w * 64 + lane) * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) bp[k] = dec[k];
@@ -244,9 +270,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             }
         }
-
-        if (have_next) stage_write(s + 1);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
