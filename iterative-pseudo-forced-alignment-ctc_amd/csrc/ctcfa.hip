@@ -92,7 +92,8 @@ const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
 
 int lds_bytes_fill(int W, int VP) {
     // emission ring (W+1 slots) + boundary columns + last-column buffer + publish sink
-    return (W + 1) * ctcfa::kRows * (VP + 1) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + ctcfa::kRows * 4 + 96 * 4;
+    return (W + 1) * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + (W + 1) * ctcfa::kBndPitch * 4 +
+           ctcfa::kRows * 4 + 512;
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
@@ -309,7 +310,7 @@ int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
     info->batch = pl->B;
     info->cols_per_lane = pl->K;
     info->waves_per_seg = pl->W;
-    info->vocab_pitch = pl->VP + 1;
+    info->vocab_pitch = pl->VP + ctcfa::kPitchPad;
     info->lds_bytes = pl->lds_fill;
     info->n_blocks_max = pl->nblk_max;
     info->workspace_bytes = pl->bits_words * 4 + pl->total_T * 4;

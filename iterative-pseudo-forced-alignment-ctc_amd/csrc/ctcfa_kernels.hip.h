@@ -35,6 +35,7 @@ namespace ctcfa {
 constexpr int kRows = 32;      // rows per block == bits per decision word
 constexpr int kBnd = 128;      // ring length (rows) of the cross-wave boundary column
 constexpr int kBndPitch = 132; // + mirror entry, padded to 16 B
+constexpr int kPitchPad = 2;   // LDS row = VP + 2 entries: 16-B aligned rows, banks rotate by 4 per row
 constexpr float kProbMax = -1000000000.0f;   // Cython sentinel (prob_max)
 constexpr float kMaxProb = -10000000000.0f;  // config.max_prob on the NumPy side
 
@@ -83,7 +84,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int preamble) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int PITCH = VP + 1;
+    constexpr int PITCH = VP + kPitchPad;  // row pitch in (e, m) entries; entry VP = start-column pseudo label
     constexpr int SLOT_BYTES = kRows * PITCH * 8;
 
     const int tid = threadIdx.x;
@@ -103,7 +104,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     //   bnd   [(W+1)][kBndPitch] floats  boundary columns; physical index p holds row t with
     //                                    (t-1) % 128 == p-1, p == 0 mirrors p == 128
     //   lcbuf [32] floats                last label column of the current block (owner wave)
-    //   sink  [96] floats                target of the lanes that publish nothing
+    //   sink  512 B                      target of the lanes that publish nothing
     const uint32_t bnd_base = static_cast<uint32_t>(NS * SLOT_BYTES);
     const uint32_t lcbuf_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
     const uint32_t sink_base = lcbuf_base + kRows * 4;
@@ -116,57 +117,143 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 
     if (w == W) {
         // ============================ producer wave ===========================================
-        // Block jb = rows t in [32*jb + 1, 32*jb + 32].  Per pass the wave covers 64/VP rows
-        // (VP <= 64) or half a row (VP == 128); CH loads are in flight before the first use.
+        // Block jb = rows t in [32*jb + 1, 32*jb + 32].  One pass of the wave covers 64/VP rows
+        // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
+        // waves (registers double-buffered), so HBM latency never sits inside a step.
         constexpr int PASSES = kRows * VP / 64;
-        constexpr int CH = PASSES < 16 ? PASSES : 16;
+        constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
-        auto stage_block = [&](int jb) {
-            unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
+        auto load_chunk = [&](int jb, int p0, float (&e)[CH]) {
             const int t0 = jb * kRows + 1;
-#pragma unroll 1
-            for (int p0 = 0; p0 < PASSES; p0 += CH) {
-                float e[CH];
 #pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const int idx = (p0 + q) * 64 + lane;  // element of the block
-                    const int sv = idx % VP;               // vocabulary entry (lane-invariant for VP <= 64)
-                    const int svc = sv < V ? sv : V - 1;
-                    int t = t0 + idx / VP;
-                    t = t < T ? t : T - 1;                 // rows past the end: re-read, discarded below
-                    e[q] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V + svc) * 4u);
-                }
-#pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const int idx = (p0 + q) * 64 + lane;
-                    const int sv = idx % VP;
-                    const int r = idx / VP;
-                    const int t = t0 + r;
-                    float lb;
-                    if constexpr (VP == 32) {  // two rows per pass: the row's blank entry via readlane
-                        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
-                        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), 32 + blank));
-                        lb = (lane < 32) ? lo : hi;
-                    } else if constexpr (VP == 64) {
-                        lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
-                    } else {
-                        const int tc = t < T ? t : T - 1;
-                        lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
-                    }
-                    const bool valid = t < T;
-                    float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
-                    if (sv < V) row[sv] = valid ? make_float2(e[q], max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
-                    if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
-                        row[VP] = make_float2(-__builtin_inff(),
-                                              (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                }
+            for (int q = 0; q < CH; ++q) {
+                const int idx = (p0 + q) * 64 + lane;  // element of the block
+                const int sv = idx % VP;               // vocabulary entry (lane-invariant for VP <= 64)
+                const int svc = sv < V ? sv : V - 1;
+                int t = t0 + idx / VP;
+                t = t < T ? t : T - 1;                 // rows past the end: re-read, discarded below
+                e[q] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V + svc) * 4u);
             }
         };
-        stage_block(0);
-        lds_barrier();
-        for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nblk) stage_block(s + 1);  // slot (s+1) % NS was last read in step s-1
+        auto write_chunk = [&](int jb, int p0, const float (&e)[CH]) {
+            unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
+            const int t0 = jb * kRows + 1;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int idx = (p0 + q) * 64 + lane;
+                const int sv = idx % VP;
+                const int r = idx / VP;
+                const int t = t0 + r;
+                float lb;
+                if constexpr (VP == 32) {  // two rows per pass: the row's blank entry via readlane
+                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
+                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), 32 + blank));
+                    lb = (lane < 32) ? lo : hi;
+                } else if constexpr (VP == 64) {
+                    lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
+                } else {
+                    const int tc = t < T ? t : T - 1;
+                    lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
+                }
+                const bool valid = t < T;
+                float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
+                if (sv < V) row[sv] = valid ? make_float2(e[q], max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
+                if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
+                    row[VP] = make_float2(-__builtin_inff(),
+                                          (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+            }
+        };
+        if (V == VP && VP <= 64) {
+            // ---- vectorised staging (the common case V == 32): a lane loads 4 consecutive
+            // entries of a row with one dwordx4, LPR lanes share a row, RPP rows per pass.
+            constexpr int LPR = VP / 4;
+            constexpr int RPP = 64 / LPR;
+            constexpr int NP = (VP <= 64) ? kRows / RPP : 1;  // 4 (VP=32) or 8 (VP=64) passes per block
+            const int lr = lane / LPR;
+            const int lv = (lane % LPR) * 4;
+            const int blank_lane = lr * LPR + blank / 4;  // lane of my row that holds the blank entry
+            const int blank_comp = blank & 3;
+            auto vload = [&](int jb, float4 (&e)[NP]) {
+                const int t0 = jb * kRows + 1 + lr;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    int t = t0 + p * RPP;
+                    t = t < T ? t : T - 1;
+                    e[p] = *reinterpret_cast<const float4*>(lpz_bytes + static_cast<uint32_t>(t * V + lv) * 4u);
+                }
+            };
+            auto vwrite = [&](int jb, const float4 (&e)[NP]) {
+                const uint32_t slot = static_cast<uint32_t>((jb % NS) * SLOT_BYTES);
+                const uint32_t ent = slot + static_cast<uint32_t>((lr * PITCH + lv) * 8);
+                // start-column entry: written by the lane holding entries 0..3, others hit a sink
+                const uint32_t spc = (lv == 0) ? slot + static_cast<uint32_t>((lr * PITCH + VP) * 8)
+                                               : sink_base + static_cast<uint32_t>(lane * 8);
+                const int t0 = jb * kRows + 1 + lr;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float4 v = e[p];
+                    const float mine = blank_comp == 0 ? v.x : (blank_comp == 1 ? v.y : (blank_comp == 2 ? v.z : v.w));
+                    const float lb = __shfl(mine, blank_lane);
+                    const bool valid = (t0 + p * RPP) < T;
+                    float4 lo = make_float4(v.x, max3f(lb, v.x, kProbMax), v.y, max3f(lb, v.y, kProbMax));
+                    float4 hi = make_float4(v.z, max3f(lb, v.z, kProbMax), v.w, max3f(lb, v.w, kProbMax));
+                    if (!valid) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+                    const float2 sp = make_float2(-__builtin_inff(),
+                                                  (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                    unsigned char* q = smem + ent + p * (RPP * PITCH * 8);
+                    *reinterpret_cast<float4*>(q) = lo;
+                    *reinterpret_cast<float4*>(q + 16) = hi;
+                    // sink offsets stay inside the 2 KB sink: p * RPP * PITCH * 8 would not
+                    *reinterpret_cast<float2*>(smem + spc + ((lv == 0) ? p * (RPP * PITCH * 8) : 0)) = sp;
+                }
+            };
+            float4 ea[NP], eb[NP];
+            vload(0, ea);
+            vwrite(0, ea);
+            if (1 < nblk) vload(1, ea);
             lds_barrier();
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 2 < nblk) vload(s + 2, eb);
+                if (s + 1 < nblk) vwrite(s + 1, ea);  // slot (s+1) % NS was last read in step s-1
+                lds_barrier();
+                if (s + 1 >= nsteps) break;
+                if (s + 3 < nblk) vload(s + 3, ea);
+                if (s + 2 < nblk) vwrite(s + 2, eb);
+                lds_barrier();
+            }
+        } else if constexpr (PASSES == CH) {
+
+            // whole block in one chunk (VP == 32): two register sets, swapped by 2x unrolling
+            float ea[CH], eb[CH];
+            load_chunk(0, 0, ea);
+            write_chunk(0, 0, ea);
+            if (1 < nblk) load_chunk(1, 0, ea);
+            lds_barrier();
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 2 < nblk) load_chunk(s + 2, 0, eb);
+                if (s + 1 < nblk) write_chunk(s + 1, 0, ea);  // slot (s+1) % NS was last read in step s-1
+                lds_barrier();
+                if (s + 1 >= nsteps) break;
+                if (s + 3 < nblk) load_chunk(s + 3, 0, ea);
+                if (s + 2 < nblk) write_chunk(s + 2, 0, eb);
+                lds_barrier();
+            }
+        } else {
+            // wide vocabulary: several chunks per block, loaded and written within the step
+            float e[CH];
+            auto stage_block = [&](int jb) {
+#pragma unroll 1
+                for (int p0 = 0; p0 < PASSES; p0 += CH) {
+                    load_chunk(jb, p0, e);
+                    write_chunk(jb, p0, e);
+                }
+            };
+            stage_block(0);
+            lds_barrier();
+            for (int s = 0; s < nsteps; ++s) {
+                if (s + 1 < nblk) stage_block(s + 1);
+                lds_barrier();
+            }
         }
         return;
     }

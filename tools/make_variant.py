@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Kernel-tuning helper (not product code): build ablated / instrumented copies of the HIP
+library into variants/<name>.so from the CURRENT sources, by textual patches.
+
+    python tools/make_variant.py base A C D stamp stamp+A ...
+
+Patches (results are WRONG for everything except `base` and `stamp`; time them with
+bench.py --no-check or tools/stamps.py):
+    A      no cross-wave boundary LDS traffic in the row loop (no bnd read, no publish)
+    C      no emission gathers (operands derived from registers)
+    D      recurrence only: drop the residual/decision math (4 VALU per cell)
+    stamp  s_memtime stamps around compute / barrier of every step (see tools/stamps.py);
+           host passes char_prob as the stamp buffer and skips the backtrack kernel
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "iterative-pseudo-forced-alignment-ctc_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-fno-slp-vectorize"]
+
+
+def sub(s, old, new, count=1):
+    assert old in s, f"patch anchor not found: {old[:60]!r}"
+    return s.replace(old, new, count)
+
+
+def patch_A(k, h):
+    k = sub(k, "*reinterpret_cast<float*>(smem + out_addr + i * 4) = prev[K - 1];", "")
+    k = sub(k, "linq[d] = *reinterpret_cast<const float*>(smem + in_addr + d * 4);", "linq[d] = kProbMax;")
+    k = sub(k, "linq[i % PF] = *reinterpret_cast<const float*>(smem + in_addr + (i + PF) * 4);", "")
+    return k, h
+
+
+def patch_C(k, h):
+    k = sub(k, "emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * (PITCH * 8));",
+            "emq[d][k] = make_float2(-1.0f - 0.001f * (float)gaddr[k], -1.0f);")
+    k = sub(k, "emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * (PITCH * 8));",
+            "{}")
+    return k, h
+
+
+def patch_D(k, h):
+    k = sub(k, """                    const float rsw = em[k].x - (nw - pl);
+                    const float rst = em[k].y - (nw - pk);
+                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);""",
+            "                    dec[k] ^= __float_as_uint(nw);")
+    return k, h
+
+
+def patch_stamp(k, h):
+    stamp_def = """
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(seg_lastcol);
+    auto stamp = [&](int s_, int q_) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        const int slot_ = (w * 16 + (s_ - 40)) * 3 + q_;
+        if (lane == 0 && blockIdx.x < 8 && s_ >= 40 && s_ < 56) stamps[slot_] = t_;
+    };
+"""
+    # define before the role split so that the producer can stamp too
+    k = sub(k, "    if (w == W) {\n        // ============================ producer wave", stamp_def + "    if (w == W) {\n        // ============================ producer wave")
+    k = sub(k, "        const int j = s - w;\n        if (j >= 0 && j < nblk) {\n            const int slot = j % NS;",
+            "        stamp(s, 0);\n        const int j = s - w;\n        if (j >= 0 && j < nblk) {\n            const int slot = j % NS;")
+    k = sub(k, "        lds_barrier();\n    }\n}", "        stamp(s, 1);\n        lds_barrier();\n        stamp(s, 2);\n    }\n}")
+    # producer (vectorised path): stamp around its work
+    k = sub(k, "                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) vwrite(s + 1, ea);  // slot (s+1) % NS was last read in step s-1\n                lds_barrier();",
+            "                stamp(s, 0);\n                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) vwrite(s + 1, ea);\n                stamp(s, 1);\n                lds_barrier();\n                stamp(s, 2);")
+    k = sub(k, "                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                lds_barrier();",
+            "                stamp(s + 1, 0);\n                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                stamp(s + 1, 1);\n                lds_barrier();\n                stamp(s + 1, 2);")
+    k = sub(k, "            if (w == wstar) {  // flush", "            if (false) {  // flush")
+    h = sub(h, "    float* lastcol_arg = pl->d_lastcol;", "    float* lastcol_arg = d_char_prob;")
+    a = h.index("    hipLaunchKernelGGL(ctcfa::backtrack_kernel")
+    b = h.index("    HIP_TRY(eng, hipGetLastError());", a)
+    h = h[:a] + "    (void)bp;\n" + h[b:]
+    return k, h
+
+
+PATCHES = {"A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
+    procs = []
+    for name in sys.argv[1:]:
+        defs = []
+        parts = []
+        for tok in name.split("+"):
+            (defs if tok.startswith("-D") else parts).append(tok)
+        k = open(os.path.join(CSRC, "ctcfa_kernels.hip.h")).read()
+        h = open(os.path.join(CSRC, "ctcfa.hip")).read()
+        for part in parts:
+            k, h = PATCHES[part](k, h)
+        d = os.path.join("/tmp", "ctcfa_variant_" + name.replace("+", "_").replace("=", "_"))
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(os.path.join(d, "p", "csrc"))
+        os.makedirs(os.path.join(d, "include"))
+        shutil.copy(os.path.join(ROOT, "include", "ctcfa.h"), os.path.join(d, "include"))
+        open(os.path.join(d, "p", "csrc", "ctcfa_kernels.hip.h"), "w").write(k)
+        open(os.path.join(d, "p", "csrc", "ctcfa.hip"), "w").write(h)
+        out = os.path.join(ROOT, "variants", "exp_" + name.replace("+", "_").replace("=", "_") + ".so")
+        procs.append((name, out, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + defs + ["ctcfa.hip", "-o", out],
+                                                  cwd=os.path.join(d, "p", "csrc"), stderr=subprocess.PIPE)))
+    for name, out, p in procs:
+        err = p.communicate()[1].decode()
+        print(name, "->", out if p.returncode == 0 else "FAILED\n" + err[-2000:])
+
+
+if __name__ == "__main__":
+    main()

@@ -36,19 +36,19 @@ for _ in range(3):
                     d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 raw = d_cp.cpu().numpy().reshape(B, T)
-nblk = (T - 1 + 31) // 32
-nsteps = nblk + W - 1
-for seg in range(2):
-    st = raw[seg].view(np.uint64)
-    n = min(len(st) // 6, W * nsteps)
-    st = st[: n * 6].reshape(-1, 6).astype(np.int64)
-    for w in range(W):
-        rows = st[w * nsteps:(w + 1) * nsteps]
-        rows = rows[(rows > 0).all(axis=1)]
-        if len(rows) < 30:
+for seg in range(1):
+    st = raw[seg].view(np.uint64)[: (W + 1) * 16 * 3].reshape(W + 1, 16, 3).astype(np.int64)
+    t_ref = st[0, 0, 0]
+    for w in range(W + 1):
+        rows = st[w]
+        ok = (rows > 0).all(axis=1)
+        if ok.sum() < 8:
+            print(f"wave {w}: no stamps")
             continue
-        mid = rows[10:-10]
-        d = [np.median(mid[:, i + 1] - mid[:, i]) for i in range(5)]
-        step = np.median(mid[1:, 0] - mid[:-1, 0])
-        print(f"seg {seg} wave {w}: step {step:.0f} cyc = store_dec+stage_load {d[0]:.0f} + compute {d[1]:.0f} "
-              f"+ vmcnt_wait {d[2]:.0f} + stage_write {d[3]:.0f} + barrier {d[4]:.0f}  (K={K}, W={W})")
+        rows = rows[ok]
+        work = np.median(rows[:, 1] - rows[:, 0])
+        bar = np.median(rows[:, 2] - rows[:, 1])
+        step = np.median(rows[1:, 0] - rows[:-1, 0])
+        role = "producer" if w == W else "compute "
+        print(f"wave {w:2d} {role}: step {step:.0f} cyc = work {work:.0f} + barrier {bar:.0f}   "
+              f"(work ends at +{np.median(rows[:, 1] - st[0, ok, 0]):.0f} after wave 0 starts the step)  K={K} W={W}")
