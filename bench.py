@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--cols-per-lane", type=int, default=int(os.environ.get("CTCFA_K", "0")))
     ap.add_argument("--cpu-sample", type=int, default=256, help="segments timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of segment boundaries")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream: fill then backtrack per step (default: backtrack of step k overlaps fill of k+1)")
     ap.add_argument("--no-check", action="store_true",
                     help="kernel-tuning only: skip the status/parity gate (ablated builds give wrong results)")
     return ap.parse_args()
@@ -79,25 +81,51 @@ def main():
     d_lpz = torch.from_numpy(lpz.reshape(-1)).to(dev)
     d_lab = torch.from_numpy(gt.astype(np.int32).reshape(-1)).to(dev)
     d_ub = torch.from_numpy(ub.astype(np.int32).reshape(-1)).to(dev)
-    d_fol = torch.empty(B * C, dtype=torch.int32, device=dev)
-    d_cp = torch.empty(B * T, dtype=torch.float32, device=dev)
-    d_seg = torch.empty(3, B * U, dtype=torch.float64, device=dev)
-    d_te = torch.empty(B, dtype=torch.int32, device=dev)
-    d_status = torch.empty(B, dtype=torch.int32, device=dev)
+    def alloc_outputs():
+        return dict(fol=torch.empty(B * C, dtype=torch.int32, device=dev),
+                    cp=torch.empty(B * T, dtype=torch.float32, device=dev),
+                    seg=torch.empty(3, B * U, dtype=torch.float64, device=dev),
+                    te=torch.empty(B, dtype=torch.int32, device=dev),
+                    status=torch.empty(B, dtype=torch.int32, device=dev))
+
+    # consecutive steps write different output sets (pipelined mode keeps two steps in flight)
+    outs = [alloc_outputs(), alloc_outputs()]
     gathered = torch.empty(world, 3, B * U, dtype=torch.float64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    pipelined = not args.serial
+    do_gather = world > 1 and not args.no_gather
+    n_calls = [0]
+
+    def gather(o):
+        # the path's only exchange: gather the final segment boundaries (the role of
+        # merge_aligned_files.py:17-25), on its own stream so it overlaps later steps
+        comm.wait_stream(stream)
+        with torch.cuda.stream(comm):
+            dist.all_gather_into_tensor(gathered.view(-1), o["seg"].view(-1))
 
     def step():
-        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), d_fol.data_ptr(),
-                        d_cp.data_ptr(), None, d_seg[0].data_ptr(), d_seg[1].data_ptr(),
-                        d_seg[2].data_ptr(), d_te.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
-        if world > 1 and not args.no_gather:
-            # the path's only exchange: gather the final segment boundaries (role of
-            # merge_aligned_files.py:17-25), on a side stream so it overlaps the next step
-            side.wait_stream(stream)
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered.view(-1), d_seg.view(-1))
+        i = n_calls[0]
+        n_calls[0] += 1
+        o = outs[i & 1]
+        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(),
+                        o["cp"].data_ptr(), None, o["seg"][0].data_ptr(), o["seg"][1].data_ptr(),
+                        o["seg"][2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(),
+                        stream.cuda_stream, pipelined=pipelined)
+        if do_gather:
+            if not pipelined:
+                gather(o)
+            elif i >= 2:
+                gather(outs[i & 1])  # results of step i-2: complete on `stream` once this call has been enqueued
+
+    def drain():
+        if pipelined:
+            plan.flush(stream.cuda_stream)
+            if do_gather:
+                for k in range(min(2, n_calls[0])):
+                    gather(outs[(n_calls[0] - 1 - k) & 1])
+        if comm is not None:
+            stream.wait_stream(comm)
 
     def barrier():
         if world > 1:
@@ -106,14 +134,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     plan.set_timing(min(args.steps, 1024))
+    n_calls[0] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if side is not None:
-        stream.wait_stream(side)
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -124,6 +153,8 @@ def main():
     fill_ms, bt_ms = plan.get_timings(n_timed)
 
     # ---- parity gate on the timed inputs (a sample; the full sweep is tests/ -m gpu) -------
+    last = outs[(args.steps - 1) & 1]
+    d_status, d_fol, d_seg, d_cp = last["status"], last["fol"], last["seg"], last["cp"]
     status = d_status.cpu().numpy()
     assert args.no_check or (status == 0).all(), "non-OK status in the benchmark batch"
     parity = None
@@ -172,7 +203,8 @@ def main():
                                    % (B, T, V, C, U),
                        "segments_per_gpu": B, "frames": T, "vocab": V, "label_columns": C,
                        "cols_per_lane": info["cols_per_lane"], "waves_per_segment": info["waves_per_seg"],
-                       "parallelism": f"segment-sharded x{world}", "parity": parity},
+                       "parallelism": f"segment-sharded x{world}", "parity": parity,
+                       "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
             "roofline": {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": alg,

@@ -119,6 +119,22 @@ int ctcfa_plan_run_device(ctcfa_plan* plan, const float* d_lpz, const int32_t* d
                           double* d_seg_end, double* d_seg_score, int32_t* d_t_end,
                           int32_t* d_status, void* stream);
 
+/*
+ * Pipelined variant for back-to-back batches: the fill kernel of this call is enqueued on
+ * `stream`, the backtrack kernel on a stream the plan owns, so that the (latency-bound,
+ * one-workgroup-per-segment) backtrack of call k overlaps the fill of call k+1.  The plan
+ * alternates between two workspaces.  Outputs of call k are complete on `stream` only
+ * after the NEXT-BUT-ONE pipelined call or after ctcfa_plan_flush(plan, stream), which makes
+ * `stream` wait for every outstanding backtrack; give consecutive calls different output
+ * buffers.  Same arguments as ctcfa_plan_run_device.
+ */
+int ctcfa_plan_run_pipelined(ctcfa_plan* plan, const float* d_lpz, const int32_t* d_labels,
+                             const int32_t* d_utt_begin, int32_t* d_frame_of_label,
+                             float* d_char_prob, int32_t* d_state, double* d_seg_start,
+                             double* d_seg_end, double* d_seg_score, int32_t* d_t_end,
+                             int32_t* d_status, void* stream);
+int ctcfa_plan_flush(ctcfa_plan* plan, void* stream);
+
 /* Kernel timing with HIP events recorded on the stream the kernels run on.
  * set_timing(slots): keep the events of the last `slots` runs (0 = off, the default).
  * get_timings(n, ...): durations [ms] of the last n runs, oldest first; synchronises

@@ -23,7 +23,8 @@ FLAG_BLANK_TRANSITION_COST_ZERO, FLAG_PREAMBLE_TRANSITION_COST_ZERO, FLAG_BACKTR
 EXPORTS = (
     "ctcfa_version", "ctcfa_status_string", "ctcfa_engine_create", "ctcfa_engine_destroy",
     "ctcfa_last_error", "ctcfa_default_params", "ctcfa_plan_create", "ctcfa_plan_destroy",
-    "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_get_timings",
+    "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_run_pipelined", "ctcfa_plan_flush",
+    "ctcfa_plan_get_timings",
     "ctcfa_plan_set_timing", "ctcfa_align_batch",
 )
 
@@ -92,6 +93,8 @@ def load():
     lib.ctcfa_plan_destroy.restype = None
     lib.ctcfa_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
     lib.ctcfa_plan_run_device.argtypes = [vp] + [vp] * 12
+    lib.ctcfa_plan_run_pipelined.argtypes = [vp] + [vp] * 12
+    lib.ctcfa_plan_flush.argtypes = [vp, vp]
     lib.ctcfa_plan_get_timings.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]
     lib.ctcfa_plan_set_timing.argtypes = [vp, ctypes.c_int]
@@ -244,9 +247,15 @@ class Plan:
         return np.array(a[:], np.float64), np.array(b[:], np.float64)
 
     def run_device(self, d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start,
-                   d_seg_end, d_seg_score, d_t_end, d_status, stream=None):
+                   d_seg_end, d_seg_score, d_t_end, d_status, stream=None, pipelined=False):
         """All arguments are raw device addresses (ints) or None; ``stream`` a hipStream_t value."""
         args = [d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start, d_seg_end,
                 d_seg_score, d_t_end, d_status, stream]
-        rc = self._lib.ctcfa_plan_run_device(self._h, *[ctypes.c_void_p(a) if a else None for a in args])
-        self._eng._check(rc, "ctcfa_plan_run_device")
+        fn = self._lib.ctcfa_plan_run_pipelined if pipelined else self._lib.ctcfa_plan_run_device
+        rc = fn(self._h, *[ctypes.c_void_p(a) if a else None for a in args])
+        self._eng._check(rc, "ctcfa_plan_run_pipelined" if pipelined else "ctcfa_plan_run_device")
+
+    def flush(self, stream=None):
+        """Make ``stream`` wait for every backtrack a pipelined run left outstanding."""
+        rc = self._lib.ctcfa_plan_flush(self._h, ctypes.c_void_p(stream) if stream else None)
+        self._eng._check(rc, "ctcfa_plan_flush")

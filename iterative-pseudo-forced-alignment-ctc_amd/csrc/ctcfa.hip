@@ -29,14 +29,21 @@ struct ctcfa_plan {
     ctcfa_engine* eng = nullptr;
     ctcfa_params prm{};
     int B = 0, V = 0, K = 0, W = 0, VP = 0;
-    int lds_fill = 0, lds_bt = 0, nblk_max = 0;
+    int lds_fill = 0, lds_bt = 0, rec_bytes = 0, nblk_max = 0;
     bool have_utt = false;
     std::vector<SegDesc> segs;
     int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
     SegDesc* d_segs = nullptr;
-    uint32_t* d_bits = nullptr;
-    float* d_lastcol = nullptr;
-    // event ring: 3 events per recorded run (start, after fill, after backtrack)
+    // workspace [2]: index 1 exists only once the pipelined entry has been used
+    uint32_t* d_bits[2] = {nullptr, nullptr};
+    float* d_lastcol[2] = {nullptr, nullptr};
+    // pipelined mode: backtrack of run k on `side` overlaps the fill of run k+1 on the caller's stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fill_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_bt_done[2] = {nullptr, nullptr};
+    bool bt_pending[2] = {false, false};
+    int64_t pipe_runs = 0;
+    // event ring: 4 events per recorded run (fill start/end, backtrack start/end)
     std::vector<hipEvent_t> ev;
     int ev_slots = 0;
     int64_t ev_runs = 0;
@@ -193,8 +200,13 @@ const char* ctcfa_last_error(const ctcfa_engine* eng) { return eng ? eng->err.c_
 void ctcfa_plan_destroy(ctcfa_plan* plan) {
     if (!plan) return;
     if (plan->d_segs) (void)hipFree(plan->d_segs);
-    if (plan->d_bits) (void)hipFree(plan->d_bits);
-    if (plan->d_lastcol) (void)hipFree(plan->d_lastcol);
+    for (int q = 0; q < 2; ++q) {
+        if (plan->d_bits[q]) (void)hipFree(plan->d_bits[q]);
+        if (plan->d_lastcol[q]) (void)hipFree(plan->d_lastcol[q]);
+        if (plan->ev_fill_done[q]) (void)hipEventDestroy(plan->ev_fill_done[q]);
+        if (plan->ev_bt_done[q]) (void)hipEventDestroy(plan->ev_bt_done[q]);
+    }
+    if (plan->side) (void)hipStreamDestroy(plan->side);
     for (auto& e : plan->ev)
         if (e) (void)hipEventDestroy(e);
     delete plan;
@@ -275,7 +287,8 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     pl->total_C = lab_off;
     pl->total_U = utt_off;
     pl->bits_words = bits_off;
-    pl->lds_bt = std::max(1, pl->nblk_max) * 8;
+    pl->rec_bytes = (std::max(1, pl->nblk_max) * 8 + 15) / 16 * 16;
+    pl->lds_bt = pl->rec_bytes + Tmax * 4;
     if (pl->lds_bt > eng->lds_limit) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "segment too long for the backtrack record buffer");
@@ -292,8 +305,8 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     } while (0)
     PLAN_TRY(hipMalloc(&pl->d_segs, sizeof(SegDesc) * (size_t)batch));
     PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
-    PLAN_TRY(hipMalloc(&pl->d_bits, sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
-    PLAN_TRY(hipMalloc(&pl->d_lastcol, sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+    PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
+    PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
     if (pl->lds_fill > 48 * 1024)
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
@@ -324,12 +337,61 @@ int ctcfa_plan_set_timing(ctcfa_plan* pl, int slots) {
     ctcfa_engine* eng = pl->eng;
     for (auto& e : pl->ev)
         if (e) (void)hipEventDestroy(e);
-    pl->ev.assign((size_t)slots * 3, nullptr);
+    pl->ev.assign((size_t)slots * 4, nullptr);
     pl->ev_slots = slots;
     pl->ev_runs = 0;
     for (auto& e : pl->ev) HIP_TRY(eng, hipEventCreate(&e));
     return CTCFA_OK;
 }
+
+namespace {
+
+struct RunArgs {
+    const float* d_lpz;
+    const int32_t* d_labels;
+    const int32_t* d_utt_begin;
+    int32_t* d_fol;
+    float* d_char_prob;
+    int32_t* d_state;
+    double *d_seg_start, *d_seg_end, *d_seg_score;
+    int32_t *d_t_end, *d_status;
+};
+
+int check_args(ctcfa_plan* pl, const RunArgs& a, bool* want_seg) {
+    ctcfa_engine* eng = pl->eng;
+    if (!a.d_lpz || !a.d_labels || !a.d_fol || !a.d_char_prob || !a.d_t_end || !a.d_status)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL device buffer");
+    *want_seg = a.d_utt_begin && a.d_seg_start && a.d_seg_end && a.d_seg_score;
+    if (*want_seg && !pl->have_utt) return set_err(eng, CTCFA_ERR_INVALID, "plan was created without U[]");
+    return CTCFA_OK;
+}
+
+int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st) {
+    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * (pl->W + 1)), pl->lds_fill, st, pl->d_segs, a.d_lpz,
+                       a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
+                       (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0);
+    HIP_TRY(pl->eng, hipGetLastError());
+    return CTCFA_OK;
+}
+
+int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hipStream_t st) {
+    BtParams bp;
+    bp.V = pl->V;
+    bp.blank = pl->prm.blank;
+    bp.Cpad = 64 * pl->K * pl->W;
+    bp.flags = pl->prm.flags;
+    bp.L = pl->prm.score_min_mean_over_L;
+    bp.rec_bytes = pl->rec_bytes;
+    bp.dur = pl->prm.index_duration;
+    hipLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st, pl->d_segs,
+                       a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws], pl->d_lastcol[ws],
+                       bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
+                       want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status);
+    HIP_TRY(pl->eng, hipGetLastError());
+    return CTCFA_OK;
+}
+
+}  // namespace
 
 int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_labels,
                           const int32_t* d_utt_begin, int32_t* d_fol, float* d_char_prob,
@@ -337,36 +399,84 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
                           double* d_seg_score, int32_t* d_t_end, int32_t* d_status, void* stream) {
     if (!pl) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
-    if (!d_lpz || !d_labels || !d_fol || !d_char_prob || !d_t_end || !d_status)
-        return set_err(eng, CTCFA_ERR_INVALID, "NULL device buffer");
-    const bool want_seg = d_utt_begin && d_seg_start && d_seg_end && d_seg_score;
-    if (want_seg && !pl->have_utt) return set_err(eng, CTCFA_ERR_INVALID, "plan was created without U[]");
+    const RunArgs a{d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state,
+                    d_seg_start, d_seg_end, d_seg_score, d_t_end, d_status};
+    bool want_seg = false;
+    int rc = check_args(pl, a, &want_seg);
+    if (rc != CTCFA_OK) return rc;
     hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
-
-    hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 3] : nullptr;
+    // a pipelined run may still be reading workspace 0 on the side stream
+    if (pl->bt_pending[0]) {
+        HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[0], 0));
+        pl->bt_pending[0] = false;
+    }
+    hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
     if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
-    float* lastcol_arg = pl->d_lastcol;
-    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * (pl->W + 1)), pl->lds_fill, st, pl->d_segs, d_lpz,
-                       d_labels, pl->d_bits, lastcol_arg, pl->V, pl->prm.blank,
-                       (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0);
-    HIP_TRY(eng, hipGetLastError());
-    if (ev) HIP_TRY(eng, hipEventRecord(ev[1], st));
-    BtParams bp;
-    bp.V = pl->V;
-    bp.blank = pl->prm.blank;
-    bp.Cpad = 64 * pl->K * pl->W;
-    bp.flags = pl->prm.flags;
-    bp.L = pl->prm.score_min_mean_over_L;
-    bp.dur = pl->prm.index_duration;
-    hipLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(64), pl->lds_bt, st, pl->d_segs, d_lpz,
-                       d_labels, want_seg ? d_utt_begin : nullptr, pl->d_bits, pl->d_lastcol, bp, d_fol,
-                       d_char_prob, d_state, d_seg_start, d_seg_end, want_seg ? d_seg_score : nullptr,
-                       d_t_end, d_status);
-    HIP_TRY(eng, hipGetLastError());
+    if ((rc = launch_fill(pl, a, 0, st)) != CTCFA_OK) return rc;
     if (ev) {
+        HIP_TRY(eng, hipEventRecord(ev[1], st));
         HIP_TRY(eng, hipEventRecord(ev[2], st));
+    }
+    if ((rc = launch_backtrack(pl, a, want_seg, 0, st)) != CTCFA_OK) return rc;
+    if (ev) {
+        HIP_TRY(eng, hipEventRecord(ev[3], st));
         pl->ev_runs++;
     }
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_labels,
+                             const int32_t* d_utt_begin, int32_t* d_fol, float* d_char_prob,
+                             int32_t* d_state, double* d_seg_start, double* d_seg_end,
+                             double* d_seg_score, int32_t* d_t_end, int32_t* d_status, void* stream) {
+    if (!pl) return CTCFA_ERR_INVALID;
+    ctcfa_engine* eng = pl->eng;
+    const RunArgs a{d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state,
+                    d_seg_start, d_seg_end, d_seg_score, d_t_end, d_status};
+    bool want_seg = false;
+    int rc = check_args(pl, a, &want_seg);
+    if (rc != CTCFA_OK) return rc;
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
+    if (!pl->side) {  // first use: second workspace, side stream, hand-over events
+        HIP_TRY(eng, hipSetDevice(eng->device));
+        HIP_TRY(eng, hipMalloc(&pl->d_bits[1], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
+        HIP_TRY(eng, hipMalloc(&pl->d_lastcol[1], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+        for (int q = 0; q < 2; ++q) {
+            HIP_TRY(eng, hipEventCreateWithFlags(&pl->ev_fill_done[q], hipEventDisableTiming));
+            HIP_TRY(eng, hipEventCreateWithFlags(&pl->ev_bt_done[q], hipEventDisableTiming));
+        }
+        HIP_TRY(eng, hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
+    }
+    const int q = (int)(pl->pipe_runs & 1);
+    // workspace q was last read by the backtrack of run k-2
+    if (pl->bt_pending[q]) HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[q], 0));
+    hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
+    if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
+    if ((rc = launch_fill(pl, a, q, st)) != CTCFA_OK) return rc;
+    if (ev) HIP_TRY(eng, hipEventRecord(ev[1], st));
+    HIP_TRY(eng, hipEventRecord(pl->ev_fill_done[q], st));
+    HIP_TRY(eng, hipStreamWaitEvent(pl->side, pl->ev_fill_done[q], 0));
+    if (ev) HIP_TRY(eng, hipEventRecord(ev[2], pl->side));
+    if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side)) != CTCFA_OK) return rc;
+    if (ev) {
+        HIP_TRY(eng, hipEventRecord(ev[3], pl->side));
+        pl->ev_runs++;
+    }
+    HIP_TRY(eng, hipEventRecord(pl->ev_bt_done[q], pl->side));
+    pl->bt_pending[q] = true;
+    pl->pipe_runs++;
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
+    if (!pl) return CTCFA_ERR_INVALID;
+    ctcfa_engine* eng = pl->eng;
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
+    for (int q = 0; q < 2; ++q)
+        if (pl->bt_pending[q]) {
+            HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[q], 0));
+            pl->bt_pending[q] = false;
+        }
     return CTCFA_OK;
 }
 
@@ -375,11 +485,11 @@ int ctcfa_plan_get_timings(ctcfa_plan* pl, int n, float* fill_ms, float* backtra
     ctcfa_engine* eng = pl->eng;
     for (int i = 0; i < n; ++i) {
         const int64_t run = pl->ev_runs - n + i;
-        hipEvent_t* ev = &pl->ev[(size_t)(run % pl->ev_slots) * 3];
-        HIP_TRY(eng, hipEventSynchronize(ev[2]));
+        hipEvent_t* ev = &pl->ev[(size_t)(run % pl->ev_slots) * 4];
+        HIP_TRY(eng, hipEventSynchronize(ev[3]));
         float a = 0.f, b = 0.f;
         HIP_TRY(eng, hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIP_TRY(eng, hipEventElapsedTime(&b, ev[1], ev[2]));
+        HIP_TRY(eng, hipEventElapsedTime(&b, ev[2], ev[3]));
         if (fill_ms) fill_ms[i] = a;
         if (backtrack_ms) backtrack_ms[i] = b;
     }

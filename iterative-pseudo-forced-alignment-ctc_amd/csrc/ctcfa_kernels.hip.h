@@ -362,39 +362,44 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 }
 
 // ---------------------------------------------------------------------------------------
-// Backtrack + per-frame outputs + utterance scoring.  grid = B, block = 64 (one wave).
+// Backtrack + per-frame outputs + utterance scoring.  grid = B, block = kBtThreads (4 waves).
+//   phase 0  end cell: first maximum of the last column            (all threads)
+//   phase A  the walk: one scalar step per run of STAYs            (wave 0; others wait)
+//   phase B  char_probs / state / frame_of_label, lanes = frames   (all threads)
+//   phase C  determine_utterance_segments, utterances over waves, lanes = window starts
+// dynamic LDS: rec[nblk] (entry column, switch mask per 32-row block) + char_probs copy [T]
 // ---------------------------------------------------------------------------------------
+constexpr int kBtThreads = 256;
+
 struct BtParams {
     int V, blank, Cpad;
     uint32_t flags;
     int L;            // score_min_mean_over_L
+    int rec_bytes;    // bytes reserved for rec[] (multiple of 16) in dynamic LDS
     double dur;       // index_duration
 };
 
-__device__ __forceinline__ double np_pairwise_sum_le128(const float* __restrict__ a, int n) {
-    // NumPy's pairwise summation for n <= 128 (fp64 accumulate of fp32-exact values)
-    auto ld = [&](int i) {
-        return (double)__hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+__device__ __forceinline__ double np_pairwise_sum_le128(const float* a, int n) {
+    // NumPy's pairwise summation for n <= 128 (fp64 accumulate of fp32-exact values), LDS input
     if (n < 8) {
         double res = 0.0;
-        for (int i = 0; i < n; ++i) res += ld(i);
+        for (int i = 0; i < n; ++i) res += (double)a[i];
         return res;
     }
     double r[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = ld(q);
+    for (int q = 0; q < 8; ++q) r[q] = (double)a[q];
     int i;
     for (i = 8; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] += ld(i + q);
+        for (int q = 0; q < 8; ++q) r[q] += (double)a[i + q];
     }
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res += ld(i);
+    for (; i < n; ++i) res += (double)a[i];
     return res;
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(kBtThreads)
 backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                  const int32_t* __restrict__ labels, const int32_t* __restrict__ utt_begin,
                  const uint32_t* __restrict__ bits, const float* __restrict__ lastcol,
@@ -403,8 +408,15 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
                  double* __restrict__ seg_end, double* __restrict__ seg_score,
                  int32_t* __restrict__ t_end_out, int32_t* __restrict__ status_out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    int2* rec = reinterpret_cast<int2*>(smem);  // per block: (entry column, switch mask)
-    const int lane = threadIdx.x;
+    __shared__ float red_v[kBtThreads / 64];
+    __shared__ int red_t[kBtThreads / 64];
+    __shared__ int sh_misc[2];  // [0] t_end, [1] bad
+    int2* rec = reinterpret_cast<int2*>(smem);                   // per block: (entry column, switch mask)
+    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes);   // char_probs of this segment
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = kBtThreads / 64;
     const SegDesc sd = segs[blockIdx.x];
     const int T = sd.T, C = sd.C, U = sd.U, shift = sd.shift, V = p.V;
     const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
@@ -415,18 +427,18 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
     const bool want_seg = (utt_begin != nullptr) && (seg_score != nullptr) && U > 0;
 
     auto fail = [&](int code) {
-        for (int c = lane; c < C; c += 64) fol[c] = 0;
-        for (int t = lane; t < T; t += 64) {
+        for (int c = tid; c < C; c += kBtThreads) fol[c] = 0;
+        for (int t = tid; t < T; t += kBtThreads) {
             cp[t] = 0.0f;
             if (st) st[t] = -2;
         }
         if (want_seg)
-            for (int u = lane; u < U; u += 64) {
+            for (int u = tid; u < U; u += kBtThreads) {
                 seg_start[sd.utt_off + u] = 0.0;
                 seg_end[sd.utt_off + u] = 0.0;
                 seg_score[sd.utt_off + u] = 0.0;
             }
-        if (lane == 0) {
+        if (tid == 0) {
             status_out[sd.seg_index] = code;
             t_end_out[sd.seg_index] = -1;
         }
@@ -436,87 +448,108 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
         return;
     }
 
-    // ---- end cell: first maximum of the last column (lastMax/lastArgMax of the fill) -----
-    int t_end;
+    // ---- phase 0: first maximum of the last column (lastMax/lastArgMax of the fill) --------
     {
         const float* lc = lastcol + sd.frm_off;
-        float bv = kProbMax;  // table[0, C-1]
-        int bt = 0;
-        for (int t = lane; t < T; t += 64) {
-            const float v = (t == 0) ? kProbMax : lc[t];
-            if (t == lane || v > bv) {  // first element initialises, then strict '>'
-                if (t == lane) { bv = v; bt = t; }
-                else { bv = v; bt = t; }
+        float bv = -__builtin_inff();
+        int bt = 0x7fffffff;
+        for (int t = tid; t < T; t += kBtThreads) {
+            const float v = (t == 0) ? kProbMax : lc[t];  // table[0, C-1] = -1e9
+            if (bt == 0x7fffffff || v > bv) {             // ascending t per thread: strict '>' keeps the first
+                bv = v;
+                bt = t;
             }
         }
-        if (lane >= T) { bv = -__builtin_inff(); bt = 0x7fffffff; }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const float ov = __shfl_xor(bv, off);
             const int ot = __shfl_xor(bt, off);
-            if (ov > bv || (ov == bv && ot < bt)) { bv = ov; bt = ot; }
-        }
-        t_end = __builtin_amdgcn_readfirstlane(bt);
-        if (p.flags & 4u) t_end = T - 1;
-    }
-
-    // ---- phase A: scalar walk, one step per run of STAYs (find-first-set on the word) ----
-    const int nblk = (T - 1 + kRows - 1) / kRows;
-    for (int j = lane; j < nblk; j += 64) rec[j] = make_int2(-1, 0);
-    __syncthreads();
-    int pc = C - 1 + shift;
-    int bad = 0;
-    if (t_end >= 1) {
-        int j = (t_end - 1) >> 5;
-        int b0 = 31 - ((t_end - 1) & 31);
-        const uint32_t* seg_bits = bits + sd.bits_off;
-        // lane i holds the decision word of column (base - i) for the block being walked;
-        // the next block's 64 candidate columns are fetched before the walk starts, so the
-        // HBM/L2 latency of one block overlaps the walk of the previous one.
-        auto fetch = [&](int jb, int base) -> uint32_t {
-            const int col = base - lane;
-            return (jb >= 0 && col >= 0) ? seg_bits[(int64_t)jb * p.Cpad + col] : 0u;
-        };
-        int base = pc;
-        uint32_t wl = fetch(j, base);
-        while (j >= 0) {
-            const int cstart = pc;
-            const int next_base = pc;
-            const uint32_t wl_next = fetch(j - 1, next_base);
-            uint32_t S = 0;
-            if (pc - shift > 0) {
-                for (;;) {
-                    uint32_t wv = __builtin_amdgcn_readlane(wl, base - pc);
-                    if (pc - shift <= 0) wv = 0;  // start column: always STAY
-                    const uint32_t m = (b0 < 32) ? (wv & (0xffffffffu << b0)) : 0u;
-                    if (m == 0) break;
-                    const int b1 = __builtin_ctz(m);
-                    S |= 1u << b1;
-                    pc -= 1;
-                    b0 = b1 + 1;
-                    if (b0 >= 32) break;
-                }
+            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
+                bv = ov;
+                bt = ot;
             }
-            if (lane == 0) rec[j] = make_int2(cstart, (int)S);
-            --j;
-            b0 = 0;
-            wl = wl_next;
-            base = next_base;
         }
-        if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
-    } else {
-        bad = (pc - shift > 0);
+        if (lane == 0) {
+            red_v[wave] = bv;
+            red_t[wave] = bt;
+        }
     }
-    if (bad) {
+    const int nblk = (T - 1 + kRows - 1) / kRows;
+    for (int j = tid; j < nblk; j += kBtThreads) rec[j] = make_int2(-1, 0);
+    for (int c = tid; c < C; c += kBtThreads) fol[c] = 0;
+    __syncthreads();
+
+    // ---- phase A (wave 0): the walk, one scalar step per run of STAYs ----------------------
+    if (wave == 0) {
+        float bv = red_v[0];
+        int bt = red_t[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) {
+            const float ov = red_v[q];
+            const int ot = red_t[q];
+            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
+                bv = ov;
+                bt = ot;
+            }
+        }
+        int t_end = __builtin_amdgcn_readfirstlane(bt);
+        if (p.flags & 4u) t_end = T - 1;
+        int pc = C - 1 + shift;
+        int bad = 0;
+        if (t_end >= 1) {
+            int j = (t_end - 1) >> 5;
+            int b0 = 31 - ((t_end - 1) & 31);
+            const uint32_t* seg_bits = bits + sd.bits_off;
+            // lane i holds the decision word of column (base - i) of the block being walked; the
+            // next block's 64 candidate columns are requested before the walk of this one starts
+            auto fetch = [&](int jb, int base) -> uint32_t {
+                const int col = base - lane;
+                return (jb >= 0 && col >= 0) ? seg_bits[(int64_t)jb * p.Cpad + col] : 0u;
+            };
+            int base = pc;
+            uint32_t wl = fetch(j, base);
+            while (j >= 0) {
+                const int cstart = pc;
+                const int next_base = pc;
+                const uint32_t wl_next = fetch(j - 1, next_base);
+                uint32_t S = 0;
+                if (pc - shift > 0) {
+                    for (;;) {
+                        uint32_t wv = __builtin_amdgcn_readlane(wl, base - pc);
+                        if (pc - shift <= 0) wv = 0;  // start column: always STAY
+                        const uint32_t m = (b0 < 32) ? (wv & (0xffffffffu << b0)) : 0u;
+                        if (m == 0) break;
+                        const int b1 = __builtin_ctz(m);
+                        S |= 1u << b1;
+                        pc -= 1;
+                        b0 = b1 + 1;
+                        if (b0 >= 32) break;
+                    }
+                }
+                if (lane == 0) rec[j] = make_int2(cstart, (int)S);
+                --j;
+                b0 = 0;
+                wl = wl_next;
+                base = next_base;
+            }
+            if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
+        } else {
+            bad = (pc - shift > 0);
+        }
+        if (lane == 0) {
+            sh_misc[0] = t_end;
+            sh_misc[1] = bad;
+        }
+    }
+    __syncthreads();
+    const int t_end = sh_misc[0];
+    if (sh_misc[1]) {
         fail(2);
         return;
     }
-    __syncthreads();
 
-    // ---- phase B: per-frame outputs, lanes = frames -----------------------------------
-    for (int c = lane; c < C; c += 64) fol[c] = 0;
-    __syncthreads();
-    for (int t = lane; t < T; t += 64) {
+    // ---- phase B: per-frame outputs, lanes = frames ---------------------------------------
+    for (int t = tid; t < T; t += kBtThreads) {
         float prob = 0.0f;
         int s_lab = -2;
         if (t >= 1 && t <= t_end) {
@@ -546,9 +579,10 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             }
         }
         cp[t] = prob;
+        cps[t] = prob;
         if (st) st[t] = s_lab;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         status_out[sd.seg_index] = 0;
         t_end_out[sd.seg_index] = t_end;
     }
@@ -556,14 +590,14 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
     __threadfence_block();
     __syncthreads();
 
-    // ---- phase C: determine_utterance_segments, lanes = window starts ------------------
+    // ---- phase C: determine_utterance_segments; utterances over waves, lanes = windows ------
     const int32_t* ub = utt_begin + sd.utt_off + sd.seg_index;
     auto tim = [&](int c) {
         if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
         return (double)__hip_atomic_load(fol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * p.dur;
     };
     const int n = p.L;
-    for (int u = 0; u < U; ++u) {
+    for (int u = wave; u < U; u += NW) {
         const int b = ub[u], e = ub[u + 1];
         const double mid_b = (tim(b) + tim(b - 1)) / 2;
         const double sb = tim(b + 1) - 0.5;
@@ -580,14 +614,14 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             long long lo = start_t < 0 ? 0 : start_t, hi = end_t > T ? T : end_t;
             if (lo > T) lo = T;
             if (hi < lo) hi = lo;
-            min_avg = np_pairwise_sum_le128(cp + lo, (int)(hi - lo)) / (double)(hi - lo);
+            min_avg = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
         } else {
             double local = 0.0;
             for (long long t0 = start_t + lane; t0 < end_t - n; t0 += 64) {
                 long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
                 if (lo > T) lo = T;
                 if (hi < lo) hi = lo;
-                const double m = np_pairwise_sum_le128(cp + lo, (int)(hi - lo)) / (double)(hi - lo);
+                const double m = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
                 if (m < local) local = m;
             }
 #pragma unroll
