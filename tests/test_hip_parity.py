@@ -218,3 +218,107 @@ def test_speechbrain_protocol_str_task(pkg, oracle):
     for f, s, e, sc in zip(fields, o["seg_start"], o["seg_end"], o["seg_score"]):
         assert f[2] == f"{s:.2f}" and f[3] == f"{e:.2f}"
         assert abs(float(f[4]) - sc) <= SCORE_TOL + 5e-5
+
+
+def test_golden_vectors(pkg):
+    """HIP path against the committed fixtures (tests/golden/dp_vectors.npz; provenance:
+    restatement -- see tests/golden/make_dp_goldens.py).  No oracle in the loop."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dp_vectors.npz"))
+    for name in g["names"]:
+        blank, pre, maxt, L = (int(x) for x in g[f"{name}/cfg"])
+        config = pkg.CtcSegmentationParameters(index_duration=float(g["index_duration"]), blank=blank,
+                                               preamble_transition_cost_zero=bool(pre),
+                                               backtrack_from_max_t=bool(maxt), score_min_mean_over_L=L)
+        r = pkg.ctc_segmentation.get_segments_device(config, [g[f"{name}/lpz"]], [g[f"{name}/gt"]],
+                                                     [g[f"{name}/utt_begin"]])[0]
+        assert r["status"] == int(g[f"{name}/status"]), name
+        if r["status"] != 0:
+            continue
+        assert r["t_end"] == int(g[f"{name}/t_end"]), name
+        assert np.array_equal(r["frame_of_label"], g[f"{name}/frame_of_label"]), name
+        assert np.array_equal(r["char_prob"], g[f"{name}/char_probs"]), name
+        assert np.array_equal(r["state"], g[f"{name}/state"]), name
+        assert np.array_equal(r["seg_start"], g[f"{name}/seg_start"]) and np.array_equal(r["seg_end"], g[f"{name}/seg_end"])
+        np.testing.assert_allclose(r["seg_score"], g[f"{name}/seg_score"], rtol=0, atol=SCORE_TOL)
+
+
+def test_full_size_properties(pkg, engine):
+    """BASELINE.json configs[2] at full size (512 x 3000 x 32, C = 640) through the plan API:
+    size-independent properties instead of an oracle run -- monotone label frames, every frame
+    in (0, t_end] visited exactly once, scores <= 0, and batch-position independence
+    (the same segment placed at two batch positions gives identical results)."""
+    import torch
+    syn = pkg.synthetic
+    B, T, V, U, n = 512, 3000, 32, 22, 28
+    base = [syn.make_segment(s, T, V, U, n) for s in range(8)]
+    idx = np.arange(B) % 8
+    lpz = np.stack([base[i][0] for i in idx])
+    gt = np.stack([base[i][1] for i in idx])
+    ub = np.stack([base[i][2] for i in idx])
+    C = gt.shape[1]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    plan = engine.plan(config.to_native(), V, [T] * B, [C] * B, [U] * B)
+    dev = torch.device("cuda:0")
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.reshape(-1)).astype(dt)).to(dev)
+    d_lpz, d_lab, d_ub = d(lpz, np.float32), d(gt, np.int32), d(ub, np.int32)
+    fol = torch.empty(B * C, dtype=torch.int32, device=dev)
+    cp = torch.empty(B * T, dtype=torch.float32, device=dev)
+    st = torch.empty(B * T, dtype=torch.int32, device=dev)
+    seg = torch.empty(3, B * U, dtype=torch.float64, device=dev)
+    te = torch.empty(B, dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), fol.data_ptr(), cp.data_ptr(), st.data_ptr(),
+                    seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr(), te.data_ptr(), status.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fol, cp, st = fol.cpu().numpy().reshape(B, C), cp.cpu().numpy().reshape(B, T), st.cpu().numpy().reshape(B, T)
+    seg, te, status = seg.cpu().numpy().reshape(3, B, U), te.cpu().numpy(), status.cpu().numpy()
+    assert (status == 0).all()
+    assert (fol[:, 0] == 0).all() and (np.diff(fol[:, 1:], axis=1) > 0).all()
+    t = np.arange(T)[None, :]
+    visited = st != -2
+    assert np.array_equal(visited, (t >= 1) & (t <= te[:, None]))
+    assert (cp <= 0).all() and (seg[2] <= 0).all() and (seg[1] >= seg[0]).all()
+    for b in range(8, B):  # replicas of the 8 base segments must agree bit for bit
+        assert np.array_equal(fol[b], fol[b % 8]) and np.array_equal(cp[b], cp[b % 8])
+        assert np.array_equal(seg[:, b], seg[:, b % 8])
+    plan.close()
+
+
+def test_pipelined_runs_match_serial(pkg, engine):
+    """ctcfa_plan_run_pipelined (backtrack on the plan's side stream, two workspaces) must give
+    the results of the serial entry for every call in a sequence."""
+    import torch
+    syn = pkg.synthetic
+    batches = [[syn.make_segment(50 * k + s, 700, 32, 5, 24) for s in range(16)] for k in range(4)]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    T, C, U = [700] * 16, [len(batches[0][0][1])] * 16, [5] * 16
+    plan = engine.plan(config.to_native(), 32, T, C, U)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(batch, pipelined):
+        d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in batch])).to(dev)
+        d_lab = torch.from_numpy(np.concatenate([s[1] for s in batch]).astype(np.int32)).to(dev)
+        d_ub = torch.from_numpy(np.concatenate([s[2] for s in batch]).astype(np.int32)).to(dev)
+        o = dict(fol=torch.zeros(sum(C), dtype=torch.int32, device=dev), cp=torch.zeros(sum(T), dtype=torch.float32, device=dev),
+                 seg=torch.zeros(3, sum(U), dtype=torch.float64, device=dev), te=torch.zeros(16, dtype=torch.int32, device=dev),
+                 status=torch.zeros(16, dtype=torch.int32, device=dev), keep=(d_lpz, d_lab, d_ub))
+        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(), o["cp"].data_ptr(), None,
+                        o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(), o["te"].data_ptr(),
+                        o["status"].data_ptr(), stream, pipelined=pipelined)
+        return o
+
+    serial = []
+    for b in batches:
+        o = run(b, False)
+        torch.cuda.synchronize()
+        serial.append({k: v.cpu().numpy() for k, v in o.items() if k != "keep"})
+    piped = [run(b, True) for b in batches]
+    plan.flush(stream)
+    torch.cuda.synchronize()
+    for s, o in zip(serial, piped):
+        for k in ("fol", "cp", "seg", "te", "status"):
+            assert np.array_equal(s[k], o[k].cpu().numpy()), k
+    plan.close()

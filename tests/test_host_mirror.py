@@ -1,0 +1,88 @@
+"""CPU suite: the host mirror of the aligner protocol (no DP call, no GPU)."""
+import numpy as np
+import pytest
+
+from oracle import ctc_segmentation_twin as tw
+from tests.fakes import FakeASR
+
+
+def test_parameters_defaults_and_flags(pkg):
+    c = pkg.CtcSegmentationParameters()
+    ref = tw.CtcSegmentationParameters()
+    for k in ("max_prob", "skip_prob", "min_window_size", "max_window_size", "index_duration",
+              "score_min_mean_over_L", "space", "blank", "replace_spaces_with_blanks",
+              "blank_transition_cost_zero", "preamble_transition_cost_zero", "backtrack_from_max_t",
+              "self_transition", "start_of_ground_truth", "excluded_characters", "tokenized_meta_symbol"):
+        assert getattr(c, k) == getattr(ref, k), k
+    assert c.flags == 2
+    c.set(blank_transition_cost_zero=True)
+    assert c.flags == 3
+    with pytest.raises(ValueError):
+        c.set(not_a_field=1)
+    c2 = pkg.CtcSegmentationParameters(subsampling_factor=4, frame_duration_ms=10)
+    assert c2.index_duration_in_seconds == 0.04
+
+
+def test_prepare_token_list_matches_twin(pkg):
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        utts = [rng.integers(0, 30, size=int(rng.integers(0, 8))) for _ in range(int(rng.integers(1, 5)))]
+        a = pkg.prepare_token_list(pkg.CtcSegmentationParameters(), utts)
+        b = tw.prepare_token_list(tw.CtcSegmentationParameters(), utts)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+        assert a[0].dtype == np.int64 and a[0].shape[1] == 1
+
+
+def test_prepare_text_matches_twin(pkg):
+    chars = ["<blank>", "<unk>", "▁", "a", "b", "c", "ab", "▁a", "·"]
+    text = ["ab ca", "b", "a.b,c"]
+    for rs in (False, True):
+        a = pkg.prepare_text(pkg.CtcSegmentationParameters(char_list=list(chars), replace_spaces_with_blanks=rs), text)
+        b = tw.prepare_text(tw.CtcSegmentationParameters(char_list=list(chars), replace_spaces_with_blanks=rs), text)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert a[0].shape[1] == 7  # max piece length ("<blank>") sets the span dimension S
+
+
+def test_task_str_format(pkg):
+    t = pkg.CTCSegmentationTask(name="utt_7", text=["HOLA QUE TAL", "ADIOS"],
+                                segments=[(0.0, 1.234, -0.12345), (1.239, 2.5, -10000000000.0)])
+    lines = str(t).split("\n")
+    assert lines[0] == "utt_7_0000 utt_7 0.00 1.23 -0.1235 HOLA QUE TAL"   # fields [2],[3],[4],[-1] after split(" ", 5)
+    assert lines[1] == "utt_7_0001 utt_7 1.24 2.50 -10000000000.0000 ADIOS"
+    assert lines[2] == ""
+    t2 = pkg.CTCSegmentationTask(name="n", text=["x"], segments=[(0, 1, -1)], utt_ids=["id0"])
+    assert str(t2) == "id0 n 0.00 1.00 -1.0000 x\n"
+
+
+def test_aligner_protocol_until_the_dp(pkg):
+    asr = FakeASR(seed=1)
+    al = pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed", scoring_length=30)
+    assert al.config.score_min_mean_over_L == 30 and al.kaldi_style_text is False
+    assert al.config.char_list[0] == "<blank>" and len(al.config.char_list) == 32
+    ratio = al.estimate_samples_to_frames_ratio()
+    assert ratio == 215040 / 671                       # wav2vec2 geometry of the fake encoder
+    import torch
+    audio = torch.zeros(16000 * 3)
+    lpz = al.get_lpz(audio)
+    assert lpz.shape == ((48000 - 400) // 320 + 1, 32) and lpz.dtype == np.float32
+    np.testing.assert_allclose(np.exp(lpz).sum(1), 1.0, rtol=1e-5)
+    # list input (iterative / word level) and single-string input (search_on_speech.py:77-82)
+    task = al.prepare_segmentation_task(["HOLA", "", "QUE TAL"], lpz, "utt", 48000)
+    assert task.text == ["HOLA", "QUE TAL"] and task.utt_ids is None
+    assert task.config.index_duration == ratio / 16000
+    gt = task.ground_truth_mat[:, 0].tolist()
+    assert gt[0] == -1 and gt[1] == 0 and gt[-1] == 0 and task.utt_begin_indices[0] == 1
+    assert len(task.utt_begin_indices) == 3
+    task2 = al.prepare_segmentation_task("·HOLA·", lpz, "utt", 48000)
+    assert task2.text == ["·HOLA·"]
+    # <unk> ids (the "·") are filtered out of the label sequence
+    assert 1 not in task2.ground_truth_mat[:, 0].tolist()
+    # kaldi style
+    al2 = pkg.CTCSegmentation(asr, kaldi_style_text=True)
+    ids, text = al2._split_text("u1 HOLA\nu2 QUE TAL\nbroken")
+    assert ids == ["u1", "u2"] and text == ["HOLA", "QUE TAL"]
+    with pytest.raises(NotImplementedError):
+        pkg.CTCSegmentation(asr, time_stamps="nope")
+    kw = dict(min_window_size=80000, max_window_size=100000, gratis_blank=False, set_blank=0)  # test_ctc_segmentation.py:20-25
+    al3 = pkg.CTCSegmentation(asr, kaldi_style_text=False, **kw)
+    assert al3.config.min_window_size == 80000 and al3.config.blank == 0
