@@ -56,3 +56,87 @@ class FakeASR:
     def encode_batch(self, wavs, wav_lens):
         frames = wavs.unfold(1, 400, 320)           # [B, T, 400]
         return frames @ self._proj.to(wavs.device)  # [B, T, V]
+
+
+# ---------------------------------------------------------------------------------------
+# Scripted aligner: drives the anchor state machine without any acoustic model.  Scores are
+# a pure function of (utterance text, clip length), so that the reference's own loop
+# (tests/golden/make_anchor_goldens.py) and this repo's loop see identical "alignments".
+# ---------------------------------------------------------------------------------------
+import zlib
+
+
+class ScriptedTask:
+    def __init__(self, text, name, n_frames, speech_len):
+        self.text, self.name, self.n_frames, self.speech_len = text, name, n_frames, speech_len
+        self.segments = None
+
+    def set(self, **kw):
+        self.__dict__.update(kw)
+
+    def __str__(self):
+        out = ""
+        for i, seg in enumerate(self.segments):
+            out += f"{self.name}_{i:04} {self.name} {seg[0]:.2f} {seg[1]:.2f} {seg[2]:3.4f} {self.text[i]}\n"
+        return out
+
+
+class ScriptedAligner:
+    """Quacks like CTCSegmentation for the caller loops (get_lpz / prepare_segmentation_task /
+    get_segments).  mode: 'mixed' pseudo-random scores in [-3.5, 0], 'good' all -0.2,
+    'bad' all -3.0, 'lastbad' only the last utterance of a task is bad, 'improving*' scores
+    that get better as utterances are dropped."""
+
+    def __init__(self, mode="mixed", salt=0, fs=16000):
+        self.mode, self.salt, self.fs = mode, salt, fs
+        self.calls = []
+
+    def estimate_samples_to_frames_ratio(self):
+        return 320.0
+
+    def get_lpz(self, audio):
+        n = int(audio.shape[0])
+        return np.zeros((max(1, n // 320), 4), np.float32)
+
+    def prepare_segmentation_task(self, text, lpz, name=None, speech_len=None):
+        if isinstance(text, str):
+            text = text.splitlines()
+        text = [t for t in text if len(t)]
+        return ScriptedTask(text, name, lpz.shape[0], speech_len)
+
+    def _score(self, utt, task, i):
+        if self.mode == "good":
+            return -0.2
+        if self.mode == "bad":
+            return -3.0
+        if self.mode == "lastbad":
+            return -3.0 if i == len(task.text) - 1 else -0.3
+        if self.mode == "improving":      # fewer utterances in the window -> better scores
+            return -0.5 - 0.3 * len(task.text)
+        if self.mode == "improving_fast":
+            return -0.2 - 0.45 * len(task.text)
+        if self.mode == "improving_slow":
+            return -1.05 - 0.1 * len(task.text) - 0.01 * (zlib.crc32(utt.encode()) % 7)
+        h = zlib.crc32(f"{self.salt}|{utt}|{task.speech_len}".encode()) % 1000
+        return -3.5 * h / 1000.0
+
+    def get_segments(self, task):
+        chars = sum(len(t) for t in task.text) + len(task.text) + 1
+        self.calls.append((task.name, len(task.text), task.speech_len))
+        if chars > task.n_frames:
+            raise AssertionError("Audio is shorter than text!")
+        dur = task.speech_len / self.fs
+        total = float(sum(len(t) for t in task.text)) or 1.0
+        segs, acc = [], 0.0
+        for i, utt in enumerate(task.text):
+            d = 0.9 * dur * len(utt) / total
+            segs.append((acc + 0.01, acc + d, self._score(utt, task, i)))
+            acc += d
+        return {"segments": segs}
+
+
+class ScriptedASR:
+    """asr_model stand-in: only audio_normalizer is used by the caller loops."""
+
+    def audio_normalizer(self, audio, sr):
+        return audio[:, 0] if audio.ndim == 2 else audio
