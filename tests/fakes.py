@@ -140,3 +140,38 @@ class ScriptedASR:
 
     def audio_normalizer(self, audio, sr):
         return audio[:, 0] if audio.ndim == 2 else audio
+
+
+def oracle_backed(aligner, oracle):
+    """Test-only: make a product CTCSegmentation answer get_segments / get_segments_batch from
+    the CPU oracle instead of the HIP engine (same protocol, same result dict)."""
+    import numpy as _np
+
+    def get_segments(task):
+        cfg = task.config
+        ocfg = oracle.make_config(index_duration=cfg.index_duration_in_seconds, blank=cfg.blank,
+                                  score_min_mean_over_L=cfg.score_min_mean_over_L,
+                                  min_window_size=cfg.min_window_size, max_window_size=cfg.max_window_size,
+                                  preamble_transition_cost_zero=int(cfg.preamble_transition_cost_zero),
+                                  backtrack_from_max_t=int(cfg.backtrack_from_max_t))
+        r = oracle.get_segments(task.lpz, task.ground_truth_mat[:, 0], _np.asarray(task.utt_begin_indices), ocfg)
+        if r["status"] == 1:
+            raise AssertionError("Audio is shorter than text!")
+        if r["status"] == 2:
+            raise IndexError("backtrack left the trellis")
+        return {"name": task.name, "timings": r["timings"], "char_probs": r["char_probs"], "state_list": None,
+                "segments": list(zip(r["seg_start"].tolist(), r["seg_end"].tolist(), r["seg_score"].tolist())),
+                "done": True}
+
+    def get_segments_batch(tasks, raise_errors=False):
+        out = []
+        for t in tasks:
+            try:
+                out.append(get_segments(t))
+            except (AssertionError, IndexError) as e:
+                out.append(e)
+        return out
+
+    aligner.get_segments = get_segments
+    aligner.get_segments_batch = get_segments_batch
+    return aligner

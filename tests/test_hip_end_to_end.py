@@ -1,0 +1,79 @@
+"""GPU: the caller loops (anchor iteration over several files in lockstep, word-level and
+search rows) driven by the product aligner -- fake acoustic model on PyTorch, DP on the HIP
+engine -- against the same loops driven by the oracle.  SURVEY.md §8 rows a1-a6 end to end."""
+import importlib
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from tests.fakes import FakeASR, oracle_backed
+from tests.test_anchor import GOLD as ANCHOR_GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+class NoiseAudio:
+    """Deterministic pseudo-speech: seeded noise, so the fake encoder yields varied posteriors."""
+
+    def __init__(self, seconds, seed, sr=16000):
+        self.sample_rate, self.num_frames = sr, int(seconds * sr)
+        g = torch.Generator().manual_seed(seed)
+        self._data = torch.randn(self.num_frames, 1, generator=g) * 0.1
+
+    def load(self, frame_offset, num_frames):
+        return self._data[frame_offset:frame_offset + num_frames], self.sample_rate
+
+
+def _rows(n):
+    return [dict(r) for r in ANCHOR_GOLD["tsv_rows"][:n]]
+
+
+def test_anchor_iteration_hip_equals_oracle(pkg, oracle):
+    anchor = importlib.import_module(pkg.__name__ + ".anchor")
+    asr = FakeASR(seed=5, sharp=6.0)
+    files = [("data/x/f%d.wav" % i, 14 + 3 * i, 70.0 + 8 * i, 40 + i) for i in range(4)]
+    vad = lambda secs: [dict(Start=0.0, End=secs * 0.45, Segment_Length=secs * 0.45),
+                        dict(Start=secs * 0.5, End=secs - 1.0, Segment_Length=secs * 0.5 - 1.0)]
+    params = anchor.AnchorParams(threshold=-6.0, short_utterance_len=12, max_words_sequence=6)
+
+    def run(aligner):
+        cos = [anchor.file_alignment(asr, NoiseAudio(secs, seed), path, [dict(r, Sample_Path=path) for r in _rows(n)],
+                                     vad(secs), 320.0, params) for path, n, secs, seed in files]
+        return anchor.run_batched(cos, aligner)
+
+    hip = run(pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed", scoring_length=30))
+    ref = run(oracle_backed(pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed", scoring_length=30), oracle))
+    assert sum(len(r) for r in hip) > 20
+    for h, r in zip(hip, ref):
+        assert len(h) == len(r)
+        for a, b in zip(h, r):
+            assert a[:6] == b[:6] and a[7:] == b[7:]          # ids, times (10 ms strings -> floats), text
+            assert abs(a[6] - b[6]) <= 1e-4 + 1e-9             # confidence score
+
+
+def test_word_level_and_search_hip_equals_oracle(pkg, oracle):
+    pl = importlib.import_module(pkg.__name__ + ".pipelines")
+    tp = importlib.import_module(pkg.__name__ + ".text_prep")
+    asr = FakeASR(seed=9, sharp=6.0)
+    rows = []
+    for i, r in enumerate(_rows(24)):
+        norm = tp.normalize_transcript(str(r["Transcription"])).upper()
+        words = norm.split(" ")
+        rows.append(dict(r, Normalized_Transcription=norm, Wanted_Text=words[min(1, len(words) - 1)],
+                         Start=float(i), End=float(i) + 4.0 + (i % 3)))
+    df = pd.DataFrame(rows)
+    audio = NoiseAudio(40.0, 77)
+    opener = lambda path: audio
+    mk = lambda: pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed")
+    hip = pl.align_words(asr, mk(), df, opener=opener)
+    ref = pl.align_words(asr, oracle_backed(mk(), oracle), df, opener=opener)
+    assert len(hip) == len(ref) >= 20
+    for a, b in zip(hip, ref):
+        assert a[:5] == b[:5] and a[6:] == b[6:] and abs(a[5] - b[5]) <= 1e-4 + 1e-9
+    hip = pl.search_on_speech(asr, mk(), df, "horizonte", opener=opener)
+    ref = pl.search_on_speech(asr, oracle_backed(mk(), oracle), df, "horizonte", opener=opener)
+    assert len(hip) == len(ref) == len(df)
+    for a, b in zip(hip, ref):
+        assert a[:5] == b[:5] and a[6:] == b[6:] and abs(a[5] - b[5]) <= 1e-4 + 1e-9
