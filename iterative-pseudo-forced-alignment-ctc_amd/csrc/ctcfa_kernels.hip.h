@@ -34,7 +34,7 @@ namespace ctcfa {
 
 constexpr int kRows = 32;      // rows per block == bits per decision word
 constexpr int kBnd = 128;      // ring length (rows) of the cross-wave boundary column
-constexpr int kBndPitch = 132; // + mirror entry, padded to 16 B
+constexpr int kBndPitch = kBnd; // floats per boundary ring: index t % 128 holds row t
 constexpr int kPitchPad = 2;   // LDS row = VP + 2 entries: 16-B aligned rows, banks rotate by 4 per row
 constexpr float kProbMax = -1000000000.0f;   // Cython sentinel (prob_max)
 constexpr float kMaxProb = -10000000000.0f;  // config.max_prob on the NumPy side
@@ -101,13 +101,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
 
     // LDS after the emission ring:
-    //   bnd   [(W+1)][kBndPitch] floats  boundary columns; physical index p holds row t with
-    //                                    (t-1) % 128 == p-1, p == 0 mirrors p == 128
-    //   lcbuf [32] floats                last label column of the current block (owner wave)
-    //   sink  512 B                      target of the lanes that publish nothing
+    //   bnd    [(W+1)][128] floats  boundary columns: ring w, index t % 128 = last column of wave w-1 at row t
+    //   lcring [64] floats          last label column (owner wave), index t % 64
+    //   sink   1280 B               target of the lanes that publish nothing
     const uint32_t bnd_base = static_cast<uint32_t>(NS * SLOT_BYTES);
-    const uint32_t lcbuf_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
-    const uint32_t sink_base = lcbuf_base + kRows * 4;
+    const uint32_t lcring_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
+    const uint32_t sink_base = lcring_base + 64 * 4;
     float* bnd = reinterpret_cast<float*>(smem + bnd_base);
     const int nblk = (T - 1 + kRows - 1) / kRows;
     const int Cpad = 64 * K * W;
@@ -275,9 +274,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         dec[k] = 0u;
     }
     const int pcl = C - 1 + shift;  // padded index of the last label column
-    const int wstar = pcl / (64 * K);
+    const int wstar = pcl / (64 * K);        // wave that owns the last label column (ragged batches: <= W-1)
     const int lstar = (pcl % (64 * K)) / K;
-    const bool owns_last = (w == wstar) && (lane == lstar);
+    float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);  // .x = row 0 of every label column
 
     lds_barrier();  // block 0 staged, boundary columns initialised
 
@@ -291,39 +290,48 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #pragma unroll
             for (int k = 0; k < K; ++k) gaddr[k] += delta;
             const int q = j & 3;
-            // consumer side: row i of this block needs row t-1 -> physical q*32 + i of ring w
+            // Cross-wave boundary column, four rows per LDS instruction (an LDS instruction costs
+            // the issuing wave ~3x a VALU one).  Ring w, index t % 128 = last column of wave w-1
+            // at row t.  Consumer: row i of this block needs row t-1 = 32j+i -> one broadcast
+            // ds_read_b128 per 4 rows.  Producer: row i belongs at index 32j+1+i, so the 16-byte
+            // groups are shifted by one row: component (i+1)%4, written after rows 2, 6, .., 30;
+            // row 31 stays in pub4.x and opens the next block's first group.
             const uint32_t in_addr = bnd_base + static_cast<uint32_t>((w * kBndPitch + q * kRows) * 4);
-            // producer side: lane 63 publishes row i at physical q*32 + 1 + i of ring w+1; the
-            // owner of the last label column also keeps it in lcbuf; every other lane writes
-            // to a sink, so the row loop has one unpredicated ds_write with an immediate offset
-            uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 4);
-            if (owns_last) out_addr = lcbuf_base;
-            if (lane == 63) out_addr = bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows + 1) * 4);
+            uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 16);
+            if (w == wstar) {  // owner of the last label column: waves beyond it hold padding only,
+                               // so nothing that matters reads this wave's ring
+                if (lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
+            } else if (lane == 63 && w < wstar) {
+                out_addr = bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows) * 4);
+            }
 
             // software pipeline: operands of row i+PF are requested while row i is computed
             constexpr int PF = CTCFA_PF;
             float2 emq[PF][K];
-            float linq[PF];
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
 #pragma unroll
                 for (int k = 0; k < K; ++k)
                     emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * (PITCH * 8));
-                linq[d] = *reinterpret_cast<const float*>(smem + in_addr + d * 4);
             }
+            float4 lin4 = *reinterpret_cast<const float4*>(smem + in_addr);
+            float4 lin4_next = lin4;
 
 #pragma unroll
             for (int i = 0; i < kRows; ++i) {
                 float2 em[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
-                const float lin = linq[i % PF];
                 if (i + PF < kRows) {
 #pragma unroll
                     for (int k = 0; k < K; ++k)
                         emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * (PITCH * 8));
-                    linq[i % PF] = *reinterpret_cast<const float*>(smem + in_addr + (i + PF) * 4);
                 }
+                if (i % 4 == 0) {
+                    if (i > 0) lin4 = lin4_next;
+                    if (i + 4 < kRows) lin4_next = *reinterpret_cast<const float4*>(smem + in_addr + (i + 4) * 4);
+                }
+                const float lin = (i % 4 == 0) ? lin4.x : (i % 4 == 1) ? lin4.y : (i % 4 == 2) ? lin4.z : lin4.w;
                 const float leftv = dpp_wave_shr1(lin, prev[K - 1]);
 #pragma unroll
                 for (int k = K - 1; k >= 0; --k) {
@@ -339,26 +347,33 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
                     prev[k] = nw;
                 }
-                *reinterpret_cast<float*>(smem + out_addr + i * 4) = prev[K - 1];
+                if ((i + 1) % 4 == 0) pub4.x = prev[K - 1];
+                else if ((i + 1) % 4 == 1) pub4.y = prev[K - 1];
+                else if ((i + 1) % 4 == 2) pub4.z = prev[K - 1];
+                else {
+                    pub4.w = prev[K - 1];
+                    *reinterpret_cast<float4*>(smem + out_addr + (i - 2) * 4) = pub4;
+                }
+                // Pin this row's decisions here (empty asm = opaque use, no instruction): dec[] is
+                // consumed at the end of the block, and LLVM otherwise sinks the residual math of
+                // all 32 rows down to that store, keeping every operand alive (hundreds of spills).
+#pragma unroll
+                for (int k = 0; k < K; ++k) asm volatile("" : "+v"(dec[k]));
             }
             // decision words of this block (fire and forget: this wave never waits on vmcnt)
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + (w * 64 + lane) * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) bp[k] = dec[k];
-            if (q == 3 && lane == 63)  // mirror: physical 0 of the ring == physical 128
-                bnd[(w + 1) * kBndPitch] = prev[K - 1];
-            if (w == wstar) {  // flush this block's last-column scores (argmax of the end cell)
-                const int t = j * kRows + 1 + lane;
-                if (lane < kRows && t < T) {
-                    const uint32_t src = (lstar == 63)
-                        ? bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows + 1 + lane) * 4)
-                        : lcbuf_base + static_cast<uint32_t>(lane * 4);
-                    seg_lastcol[t] = *reinterpret_cast<const float*>(smem + src);
-                }
+            if (w == wstar) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
+                const int t = j * kRows + lane;
+                if (lane < kRows && t >= 1 && t < T)
+                    seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
             }
         }
         lds_barrier();
     }
+    // row 32*nblk (present when (T-1) % 32 == 0) is still in pub4.x
+    if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -74,10 +74,10 @@ def patch_stamp(k, h):
     k = sub(k, "                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                lds_barrier();",
             "                stamp(s + 1, 0);\n                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                stamp(s + 1, 1);\n                lds_barrier();\n                stamp(s + 1, 2);")
     k = sub(k, "            if (w == wstar) {  // flush", "            if (false) {  // flush")
-    h = sub(h, "    float* lastcol_arg = pl->d_lastcol;", "    float* lastcol_arg = d_char_prob;")
-    a = h.index("    hipLaunchKernelGGL(ctcfa::backtrack_kernel")
-    b = h.index("    HIP_TRY(eng, hipGetLastError());", a)
-    h = h[:a] + "    (void)bp;\n" + h[b:]
+    # stamps land in the caller's char_prob buffer; the backtrack kernel is not launched
+    h = sub(h, "a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,",
+            "a.d_labels, pl->d_bits[ws], a.d_char_prob, pl->V, pl->prm.blank,")
+    h = sub(h, "    if ((rc = launch_backtrack(pl, a, want_seg, 0, st)) != CTCFA_OK) return rc;", "    (void)want_seg;")
     return k, h
 
 
