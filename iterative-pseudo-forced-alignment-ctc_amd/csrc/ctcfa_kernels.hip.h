@@ -279,6 +279,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);  // .x = row 0 of every label column
 
     lds_barrier();  // block 0 staged, boundary columns initialised
+    // Three waves share a SIMD and VALU/LDS arbitration goes by priority, then age: the
+    // later-dispatched waves would always lose and every step ends at a barrier that waits for
+    // them.  Static priorities (younger half above older half, both above the light producer)
+    // even the waves out: -4 % kernel time.
+    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
 
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
     for (int s = 0; s < nsteps; ++s) {

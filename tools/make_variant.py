@@ -67,13 +67,14 @@ def patch_stamp(k, h):
     k = sub(k, "    if (w == W) {\n        // ============================ producer wave", stamp_def + "    if (w == W) {\n        // ============================ producer wave")
     k = sub(k, "        const int j = s - w;\n        if (j >= 0 && j < nblk) {\n            const int slot = j % NS;",
             "        stamp(s, 0);\n        const int j = s - w;\n        if (j >= 0 && j < nblk) {\n            const int slot = j % NS;")
-    k = sub(k, "        lds_barrier();\n    }\n}", "        stamp(s, 1);\n        lds_barrier();\n        stamp(s, 2);\n    }\n}")
+    k = sub(k, "        lds_barrier();\n    }\n    // row 32*nblk", "        stamp(s, 1);\n        lds_barrier();\n        stamp(s, 2);\n    }\n    // row 32*nblk")
     # producer (vectorised path): stamp around its work
     k = sub(k, "                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) vwrite(s + 1, ea);  // slot (s+1) % NS was last read in step s-1\n                lds_barrier();",
             "                stamp(s, 0);\n                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) vwrite(s + 1, ea);\n                stamp(s, 1);\n                lds_barrier();\n                stamp(s, 2);")
     k = sub(k, "                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                lds_barrier();",
             "                stamp(s + 1, 0);\n                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                stamp(s + 1, 1);\n                lds_barrier();\n                stamp(s + 1, 2);")
-    k = sub(k, "            if (w == wstar) {  // flush", "            if (false) {  // flush")
+    k = sub(k, "            if (w == wstar) {  // last-column scores", "            if (false) {  // last-column scores")
+    k = sub(k, "    if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;", "")
     # stamps land in the caller's char_prob buffer; the backtrack kernel is not launched
     h = sub(h, "a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,",
             "a.d_labels, pl->d_bits[ws], a.d_char_prob, pl->V, pl->prm.blank,")
