@@ -521,37 +521,44 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             int j = (t_end - 1) >> 5;
             int b0 = 31 - ((t_end - 1) & 31);
             const uint32_t* seg_bits = bits + sd.bits_off;
-            // lane i holds the decision word of column (base - i) of the block being walked; the
-            // next block's 64 candidate columns are requested before the walk of this one starts
+            // Per 32-row block: lane i holds the decision word of column (pc - i) (the path can drop
+            // at most 32 columns inside the block).  The 32x64 bit tile is transposed with one
+            // ballot per row (bit i of row mask b = "column pc-i switches at row b"), after which
+            // the walk is straight-line scalar code: p += (mask_b >> p) & 1 -- three dependent
+            // SALU ops per row, no branch.  The next block's words are requested before this
+            // block is walked, so their HBM/L2 latency overlaps the scalar chain.
             auto fetch = [&](int jb, int base) -> uint32_t {
                 const int col = base - lane;
-                return (jb >= 0 && col >= 0) ? seg_bits[(int64_t)jb * p.Cpad + col] : 0u;
+                // columns at or left of the start column (<= shift) always STAY: their bits read as 0
+                return (jb >= 0 && col - shift > 0) ? seg_bits[(int64_t)jb * p.Cpad + col] : 0u;
             };
-            int base = pc;
-            uint32_t wl = fetch(j, base);
+            uint32_t wl = fetch(j, pc);
             while (j >= 0) {
                 const int cstart = pc;
-                const int next_base = pc;
-                const uint32_t wl_next = fetch(j - 1, next_base);
+                // speculative request for the next block, relative to the column we are at now; the
+                // true entry column of that block is <= 32 lower, so re-base the lane index below
+                const uint32_t wn = fetch(j - 1, cstart);
+                const uint32_t wn2 = fetch(j - 1, cstart - 32);
                 uint32_t S = 0;
-                if (pc - shift > 0) {
-                    for (;;) {
-                        uint32_t wv = __builtin_amdgcn_readlane(wl, base - pc);
-                        if (pc - shift <= 0) wv = 0;  // start column: always STAY
-                        const uint32_t m = (b0 < 32) ? (wv & (0xffffffffu << b0)) : 0u;
-                        if (m == 0) break;
-                        const int b1 = __builtin_ctz(m);
-                        S |= 1u << b1;
-                        pc -= 1;
-                        b0 = b1 + 1;
-                        if (b0 >= 32) break;
-                    }
+                int pidx = 0;  // columns dropped so far in this block
+#pragma unroll
+                for (int bb = 0; bb < kRows; ++bb) {
+                    const unsigned long long rowmask = __builtin_amdgcn_ballot_w64(((wl >> bb) & 1u) != 0u);
+                    const uint32_t bit = (bb >= b0) ? (uint32_t)((rowmask >> pidx) & 1ull) : 0u;
+                    pidx += (int)bit;
+                    S |= bit << bb;
                 }
+                pc -= pidx;
                 if (lane == 0) rec[j] = make_int2(cstart, (int)S);
                 --j;
                 b0 = 0;
-                wl = wl_next;
-                base = next_base;
+                // next block's words for columns pc - i: lane i takes them from the two speculative
+                // loads (wn: columns cstart - i, wn2: columns cstart - 32 - i)
+                const int drop = cstart - pc;            // 0..32
+                const int src = lane + drop;             // lane of wn that holds column pc - lane
+                const uint32_t from_n = __shfl(wn, src & 63);
+                const uint32_t from_n2 = __shfl(wn2, (src - 32) & 63);
+                wl = (src < 64) ? from_n : from_n2;
             }
             if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
         } else {

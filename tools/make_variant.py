@@ -82,7 +82,18 @@ def patch_stamp(k, h):
     return k, h
 
 
-PATCHES = {"A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+def patch_btstamp(k, h):
+    """backtrack kernel: cycles of phase 0 / A / B / C of segment b into status[b], t_end[b],
+    seg_start[first utt], seg_end[first utt] (results are destroyed)."""
+    k = sub(k, "    // ---- phase 0: first maximum of the last column", "    const unsigned long long bt0 = __builtin_amdgcn_s_memtime();\n    // ---- phase 0: first maximum of the last column")
+    k = sub(k, "    // ---- phase A (wave 0): the walk", "    const unsigned long long bt1 = __builtin_amdgcn_s_memtime();\n    // ---- phase A (wave 0): the walk")
+    k = sub(k, "    // ---- phase B: per-frame outputs, lanes = frames", "    const unsigned long long bt2 = __builtin_amdgcn_s_memtime();\n    // ---- phase B: per-frame outputs, lanes = frames")
+    k = sub(k, "    if (!want_seg) return;\n    __threadfence_block();", "    const unsigned long long bt3 = __builtin_amdgcn_s_memtime();\n    if (!want_seg) return;\n    __threadfence_block();")
+    k = sub(k, "            seg_score[sd.utt_off + u] = min_avg;\n        }\n    }\n}", "            seg_score[sd.utt_off + u] = min_avg;\n        }\n    }\n    __syncthreads();\n    const unsigned long long bt4 = __builtin_amdgcn_s_memtime();\n    if (tid == 0) { status_out[sd.seg_index] = (int)(bt1 - bt0); t_end_out[sd.seg_index] = (int)(bt2 - bt1); seg_start[sd.utt_off] = (double)(bt3 - bt2); seg_end[sd.utt_off] = (double)(bt4 - bt3); }\n}")
+    return k, h
+
+
+PATCHES = {"btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
