@@ -189,6 +189,19 @@ def main():
                          f"oracle/ctc_segmentation_oracle.c, single thread, {sec:.1f} s",
                "host_cores": os.cpu_count()}
 
+    # HBM bytes per launch of the dominant kernel: PMC counters are collected in separate
+    # rocprofv3 --pmc passes (tools/collect_traffic.sh) and committed under profiles/; the
+    # figure is only valid for the default workload it was measured on.
+    traffic, traffic_src = None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if files and (B, T, V, U, n) == (512, 3000, 32, 22, 28):
+        try:
+            traffic = json.load(open(files[-1]))["fill_kernel"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 FETCH x2)"
+        except Exception:
+            traffic = None
+
     if rank == 0:
         frames_total = world * B * T * args.steps
         fps = frames_total / dt
@@ -211,7 +224,7 @@ def main():
                        "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
             "roofline": {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                          "kernel_ms_avg": float(np.mean(fill_ms)), "kernel_ms_min": float(np.min(fill_ms)),
                          "backtrack_kernel_ms_avg": float(np.mean(bt_ms))},
             "cpu_baseline": cpu,
