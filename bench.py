@@ -60,13 +60,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal mode for a 1-GPU box (not used by the driver): every rank on cuda:0, gloo instead
+    # of RCCL -- exercises the multi-rank control flow of this script without N devices.
+    rehearsal = os.environ.get("CTCFA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- synthetic workload (SURVEY §8(d) recipe), this rank's shard ----------------------
     syn = pkg.synthetic
@@ -88,8 +96,10 @@ def main():
                     te=torch.empty(B, dtype=torch.int32, device=dev),
                     status=torch.empty(B, dtype=torch.int32, device=dev))
 
-    # consecutive steps write different output sets (pipelined mode keeps two steps in flight)
-    outs = [alloc_outputs(), alloc_outputs()]
+    # consecutive steps write different output sets: the pipelined schedule keeps two steps in
+    # flight and the gather of step i-2 may still be reading while step i runs -> three sets
+    outs = [alloc_outputs(), alloc_outputs(), alloc_outputs()]
+    NSETS = len(outs)
     gathered = torch.empty(world, 3, B * U, dtype=torch.float64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -102,12 +112,18 @@ def main():
         # merge_aligned_files.py:17-25), on its own stream so it overlaps later steps
         comm.wait_stream(stream)
         with torch.cuda.stream(comm):
-            dist.all_gather_into_tensor(gathered.view(-1), o["seg"].view(-1))
+            if rehearsal:   # gloo has no all_gather_into_tensor for device tensors
+                parts = [torch.empty_like(o["seg"]) for _ in range(world)]
+                dist.all_gather(parts, o["seg"])
+            else:
+                dist.all_gather_into_tensor(gathered.view(-1), o["seg"].view(-1))
 
     def step():
         i = n_calls[0]
         n_calls[0] += 1
-        o = outs[i & 1]
+        o = outs[i % NSETS]
+        if do_gather:
+            stream.wait_stream(comm)   # the gather that last read this output set has finished
         plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(),
                         o["cp"].data_ptr(), None, o["seg"][0].data_ptr(), o["seg"][1].data_ptr(),
                         o["seg"][2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(),
@@ -116,14 +132,14 @@ def main():
             if not pipelined:
                 gather(o)
             elif i >= 2:
-                gather(outs[i & 1])  # results of step i-2: complete on `stream` once this call has been enqueued
+                gather(outs[(i - 2) % NSETS])  # step i-2: complete on `stream` once this call has been enqueued
 
     def drain():
         if pipelined:
             plan.flush(stream.cuda_stream)
             if do_gather:
                 for k in range(min(2, n_calls[0])):
-                    gather(outs[(n_calls[0] - 1 - k) & 1])
+                    gather(outs[(n_calls[0] - 1 - k) % NSETS])
         if comm is not None:
             stream.wait_stream(comm)
 
@@ -153,7 +169,7 @@ def main():
     fill_ms, bt_ms = plan.get_timings(n_timed)
 
     # ---- parity gate on the timed inputs (a sample; the full sweep is tests/ -m gpu) -------
-    last = outs[(args.steps - 1) & 1]
+    last = outs[(args.steps - 1) % NSETS]
     d_status, d_fol, d_seg, d_cp = last["status"], last["fol"], last["seg"], last["cp"]
     status = d_status.cpu().numpy()
     assert args.no_check or (status == 0).all(), "non-OK status in the benchmark batch"
