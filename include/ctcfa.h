@@ -110,7 +110,7 @@ int ctcfa_plan_get_info(const ctcfa_plan* plan, ctcfa_plan_info* info);
  * Run a plan on DEVICE-resident buffers (layout in the header comment).
  * Replaces, batched:  cython_fill_table + the backtrack loop of ctc_segmentation()
  * + determine_utterance_segments().  `stream` is a hipStream_t (NULL = the
- * engine's own stream); the call only enqueues work.
+ * default/null stream, e.g. torch's default stream); the call only enqueues work.
  * d_state, d_utt_begin, d_seg_* may be NULL (skipped).
  */
 int ctcfa_plan_run_device(ctcfa_plan* plan, const float* d_lpz, const int32_t* d_labels,

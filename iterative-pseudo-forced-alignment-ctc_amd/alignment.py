@@ -83,12 +83,16 @@ class CTCSegmentation:
     warned_about_misconfiguration = False
 
     def __init__(self, asr_model, kaldi_style_text=True, text_converter="tokenize",
-                 time_stamps="auto", engine=None, **ctc_segmentation_args):
+                 time_stamps="auto", engine=None, keep_lpz_on_device=False, **ctc_segmentation_args):
         if not hasattr(asr_model, "tokenizer"):
             raise AttributeError("The ASR model needs a tokenizer (asr_model.tokenizer)")
         self.config = CtcSegmentationParameters()
         self.asr_model = asr_model
         self._engine = engine
+        # False: get_lpz returns a host NumPy array (the reference's protocol).  True: when the
+        # model runs on a GPU the log-posteriors stay in HBM as a torch tensor and feed the DP
+        # kernels without a PCIe round trip.
+        self.keep_lpz_on_device = bool(keep_lpz_on_device)
         self._encode = asr_model.encode_batch
         mods = getattr(asr_model, "mods", None)
         decoder = getattr(mods, "decoder", None) if mods is not None else None
@@ -162,8 +166,10 @@ class CTCSegmentation:
             speech = speech.unsqueeze(0).to(device)
             wav_lens = torch.tensor([1.0]).to(device)
             enc = self._encode(speech, wav_lens)
-            lpz = self._ctc(enc).detach()
-            return lpz.squeeze(0).cpu().numpy()
+            lpz = self._ctc(enc).detach().squeeze(0)
+            if self.keep_lpz_on_device and lpz.is_cuda:
+                return lpz.to(torch.float32).contiguous()
+            return lpz.cpu().numpy()
 
     # -- text ----------------------------------------------------------------------------
     def _split_text(self, text):

@@ -403,7 +403,7 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
     bool want_seg = false;
     int rc = check_args(pl, a, &want_seg);
     if (rc != CTCFA_OK) return rc;
-    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     // a pipelined run may still be reading workspace 0 on the side stream
     if (pl->bt_pending[0]) {
         HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[0], 0));
@@ -435,7 +435,7 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     bool want_seg = false;
     int rc = check_args(pl, a, &want_seg);
     if (rc != CTCFA_OK) return rc;
-    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     if (!pl->side) {  // first use: second workspace, side stream, hand-over events
         HIP_TRY(eng, hipSetDevice(eng->device));
         HIP_TRY(eng, hipMalloc(&pl->d_bits[1], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
@@ -470,7 +470,7 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
 int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
     if (!pl) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
-    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : eng->stream;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     for (int q = 0; q < 2; ++q)
         if (pl->bt_pending[q]) {
             HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[q], 0));

@@ -77,3 +77,31 @@ def test_word_level_and_search_hip_equals_oracle(pkg, oracle):
     assert len(hip) == len(ref) == len(df)
     for a, b in zip(hip, ref):
         assert a[:5] == b[:5] and a[6:] == b[6:] and abs(a[5] - b[5]) <= 1e-4 + 1e-9
+
+
+def test_device_resident_emissions_match_host_path(pkg):
+    """keep_lpz_on_device=True: encoder output stays in HBM (torch tensor) and feeds
+    ctcfa_plan_run_device; results must equal the host-array protocol path."""
+    asr_gpu = FakeASR(seed=11, device="cuda:0")
+    asr_cpu = FakeASR(seed=11)
+    on_dev = pkg.CTCSegmentation(asr_gpu, kaldi_style_text=False, time_stamps="fixed", scoring_length=30,
+                                 keep_lpz_on_device=True)
+    on_host = pkg.CTCSegmentation(asr_cpu, kaldi_style_text=False, time_stamps="fixed", scoring_length=30)
+    audio = NoiseAudio(30.0, 123)
+    texts = [["HOLA QUE TAL", "MUY BIEN"], ["ADIOS"], ["UNO DOS TRES", "CUATRO", "CINCO SEIS"]]
+    tasks_d, tasks_h = [], []
+    for i, text in enumerate(texts):
+        clip, sr = audio.load(16000 * 5 * i, 16000 * (6 + i))
+        wav = asr_cpu.audio_normalizer(clip, sr)
+        lpz_d = on_dev.get_lpz(wav)
+        lpz_h = on_host.get_lpz(wav)
+        assert lpz_d.is_cuda and isinstance(lpz_h, np.ndarray)
+        # the same matrix up to the GPU matmul's rounding; align the DEVICE matrix on both paths
+        lpz_h = lpz_d.cpu().numpy()
+        tasks_d.append(on_dev.prepare_segmentation_task(text, lpz_d, f"u{i}", wav.shape[0]))
+        tasks_h.append(on_host.prepare_segmentation_task(text, lpz_h, f"u{i}", wav.shape[0]))
+    res_d = on_dev.get_segments_batch(tasks_d)
+    res_h = on_host.get_segments_batch(tasks_h)
+    for a, b in zip(res_d, res_h):
+        assert np.array_equal(a["timings"], b["timings"]) and np.array_equal(a["char_probs"], b["char_probs"])
+        assert a["segments"] == b["segments"] and a["state_list"] == b["state_list"]
