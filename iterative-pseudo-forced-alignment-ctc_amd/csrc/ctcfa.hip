@@ -99,7 +99,7 @@ const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
 
 int lds_bytes_fill(int W, int VP) {
     // emission ring (W+1 slots) + boundary rings + last-column ring + sink
-    return (W + 1) * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + 1280;
+    return (W + 1) * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + ctcfa::kSinkBytes + 16;
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }

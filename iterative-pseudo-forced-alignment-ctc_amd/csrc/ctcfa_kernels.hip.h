@@ -35,6 +35,7 @@ namespace ctcfa {
 constexpr int kRows = 32;      // rows per block == bits per decision word
 constexpr int kBnd = 128;      // ring length (rows) of the cross-wave boundary column
 constexpr int kBndPitch = kBnd; // floats per boundary ring: index t % 128 holds row t
+constexpr int kSinkBytes = 1280; // sink for lanes that publish nothing (64 x 16 B, plus slack)
 constexpr int kPitchPad = 2;   // LDS row = VP + 2 entries: 16-B aligned rows, banks rotate by 4 per row
 constexpr float kProbMax = -1000000000.0f;   // Cython sentinel (prob_max)
 constexpr float kMaxProb = -10000000000.0f;  // config.max_prob on the NumPy side
@@ -107,12 +108,16 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const uint32_t bnd_base = static_cast<uint32_t>(NS * SLOT_BYTES);
     const uint32_t lcring_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
     const uint32_t sink_base = lcring_base + 64 * 4;
+    // posflag (last 4 bytes of the sink area's tail): set by the producer as soon as any staged
+    // emission is not <= 0 -- from then on nobody may assume that unreachable cells are -1e9
+    volatile int* posflag = reinterpret_cast<volatile int*>(smem + sink_base + kSinkBytes);
     float* bnd = reinterpret_cast<float*>(smem + bnd_base);
     const int nblk = (T - 1 + kRows - 1) / kRows;
     const int Cpad = 64 * K * W;
     const int nsteps = nblk + W - 1;
 
     for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = kProbMax;
+    if (tid == 0) *posflag = 0;
 
     if (w == W) {
         // ============================ producer wave ===========================================
@@ -122,6 +127,10 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         constexpr int PASSES = kRows * VP / 64;
         constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
+        bool notneg = false;  // any staged emission that is not <= 0 (NaN counts)
+        auto publish_flag = [&]() {
+            if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
+        };
         auto load_chunk = [&](int jb, int p0, float (&e)[CH]) {
             const int t0 = jb * kRows + 1;
 #pragma unroll
@@ -155,6 +164,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
                 }
                 const bool valid = t < T;
+                notneg |= !(e[q] <= 0.0f);
                 float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
                 if (sv < V) row[sv] = valid ? make_float2(e[q], max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
                 if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
@@ -191,6 +201,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const float4 v = e[p];
+                    notneg |= !(max3f(v.x, v.y, __builtin_fmaxf(v.z, v.w)) <= 0.0f) | (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
                     const float mine = blank_comp == 0 ? v.x : (blank_comp == 1 ? v.y : (blank_comp == 2 ? v.z : v.w));
                     const float lb = __shfl(mine, blank_lane);
                     const bool valid = (t0 + p * RPP) < T;
@@ -209,15 +220,16 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             float4 ea[NP], eb[NP];
             vload(0, ea);
             vwrite(0, ea);
+            publish_flag();
             if (1 < nblk) vload(1, ea);
             lds_barrier();
             for (int s = 0; s < nsteps; s += 2) {
                 if (s + 2 < nblk) vload(s + 2, eb);
-                if (s + 1 < nblk) vwrite(s + 1, ea);  // slot (s+1) % NS was last read in step s-1
+                if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
                 lds_barrier();
                 if (s + 1 >= nsteps) break;
                 if (s + 3 < nblk) vload(s + 3, ea);
-                if (s + 2 < nblk) vwrite(s + 2, eb);
+                if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }
                 lds_barrier();
             }
         } else if constexpr (PASSES == CH) {
@@ -226,15 +238,16 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             float ea[CH], eb[CH];
             load_chunk(0, 0, ea);
             write_chunk(0, 0, ea);
+            publish_flag();
             if (1 < nblk) load_chunk(1, 0, ea);
             lds_barrier();
             for (int s = 0; s < nsteps; s += 2) {
                 if (s + 2 < nblk) load_chunk(s + 2, 0, eb);
-                if (s + 1 < nblk) write_chunk(s + 1, 0, ea);  // slot (s+1) % NS was last read in step s-1
+                if (s + 1 < nblk) { write_chunk(s + 1, 0, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
                 lds_barrier();
                 if (s + 1 >= nsteps) break;
                 if (s + 3 < nblk) load_chunk(s + 3, 0, ea);
-                if (s + 2 < nblk) write_chunk(s + 2, 0, eb);
+                if (s + 2 < nblk) { write_chunk(s + 2, 0, eb); publish_flag(); }
                 lds_barrier();
             }
         } else {
@@ -246,6 +259,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     load_chunk(jb, p0, e);
                     write_chunk(jb, p0, e);
                 }
+                publish_flag();
             };
             stage_block(0);
             lds_barrier();
@@ -286,10 +300,51 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(1);
 
+    // Dead zone: column c cannot reach the end cell's column C-1 from rows t > T-C+c, so the
+    // backtrack never visits those cells and they feed only other dead cells.  A wave stops
+    // after the last block in which its right-most label column is still alive (exact for any
+    // input: nothing downstream reads what is skipped; later waves only read boundary rows that
+    // are alive, or compute dead cells from stale-but-finite ring entries).
+    int jlast = nblk - 1;
+    {
+        const int cmax = ((w + 1) * 64 * K - 1) - shift;   // right-most column of this wave
+        if (cmax < C - 1) {
+            const int tdead = T - C + cmax;                // last row where cmax is alive
+            jlast = tdead >= 1 ? (tdead - 1) / kRows : -1;
+            if (jlast > nblk - 1) jlast = nblk - 1;
+        }
+    }
+    if (w > wstar) jlast = -1;  // ragged batch: this wave holds right padding only
+    // Unreachable zone: cells with c > t hold exactly -1e9 as long as every emission so far is
+    // <= 0 (log-probabilities always are; the producer's posflag says when they are not).  A wave
+    // whose left-most column is cmin idles through the blocks that end before row cmin and then
+    // starts from the state it would have computed: -1e9 in every column, -1e9 boundary rows.
+    int jfirst = 0;
+    {
+        const int cmin = w * 64 * K - shift;               // left-most column of this wave
+        if (cmin >= 1) jfirst = (cmin - 1) / kRows;
+        if (jfirst > jlast + 1) jfirst = jlast + 1;
+    }
+#ifdef CTCFA_NO_DEADZONE
+    jlast = nblk - 1;
+    jfirst = 0;
+#endif
+
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
     for (int s = 0; s < nsteps; ++s) {
         const int j = s - w;
-        if (j >= 0 && j < nblk) {
+        if (j >= 0 && j < jfirst) {
+            if (__builtin_amdgcn_readfirstlane(*posflag) == 0) {   // still provably -1e9 everywhere in this block
+                if (w == wstar) {
+                    const int t = j * kRows + lane;
+                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
+                }
+                lds_barrier();
+                continue;
+            }
+            jfirst = 0;            // emissions are not log-probabilities: compute everything from here on
+        }
+        if (j >= 0 && j <= jlast) {
             const int slot = j % NS;
             const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
             cur_slot = slot;

@@ -381,3 +381,26 @@ def test_many_random_small_cases(pkg, oracle):
     res = _run(pkg, segs)
     assert sum(r["status"] == 0 for r in res) == len(segs)
     _check(pkg, oracle, segs, res)
+
+
+@pytest.mark.parametrize("where", ["everywhere", "late", "first_row", "one_value"])
+def test_emissions_that_are_not_log_probabilities(pkg, oracle, where):
+    """The fill kernel idles through trellis regions that hold exactly -1e9 while every
+    emission so far is <= 0; positive inputs (raw logits) must switch that off -- from the
+    first block, or in the middle of a segment -- and still match the oracle bit for bit."""
+    segs = []
+    for s in range(4):
+        rng = np.random.default_rng(1500 + s)
+        T, U, n = 900 + 101 * s, 10 + s, 24
+        gt, ub = pkg.synthetic.make_labels(rng, U, n, 32)
+        lpz = pkg.synthetic.make_emissions(rng, T, 32, gt)
+        if where == "everywhere":
+            lpz = (lpz + 7.5).astype(np.float32)
+        elif where == "late":
+            lpz[T // 3:] += np.float32(9.0)
+        elif where == "first_row":
+            lpz[:2] += np.float32(11.0)
+        else:
+            lpz[40 + 13 * s, 5] = np.float32(3.25)
+        segs.append((lpz, gt, ub))
+    _check(pkg, oracle, segs, _run(pkg, segs))

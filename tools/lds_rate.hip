@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(1024) lds_kernel(unsigned long long* cyc, floa
             if (OP == 6) { asm volatile("s_mov_b64 exec, 1\n\tds_write_b128 %0, %1 offset:%2\n\ts_mov_b64 exec, -1" :: "v"(a_lane16), "v"(v4), "i"(u * 16)); }
             if (OP == 7) { f4 r; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a_gather16), "i"(u * 528)); }
             if (OP == 8) { float r; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(a_gather8), "i"(u * 264)); }
+            if (OP == 10) { float r; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(lab * 4u), "i"(u * 136)); }
+            if (OP == 11) { f2 r; asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(lab * 4u), "i"(u), "i"(u + 34)); }
             if (OP == 9) { asm volatile("s_mov_b64 exec, 1\n\tds_read_b32 %0, %1 offset:%2\n\ts_mov_b64 exec, -1" : "=v"(acc) : "v"(a_bcast), "i"(u * 4)); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -71,6 +73,8 @@ int main() {
     int* d_lab; (void)hipMalloc(&d_lab, sizeof(lab)); (void)hipMemcpy(d_lab, lab, sizeof(lab), hipMemcpyHostToDevice);
     run<0>("ds_read_b64 gather(32x8B)", d_lab);
     run<8>("ds_read_b32 gather(32x8B)", d_lab);
+    run<10>("ds_read_b32 gather(32x4B)", d_lab);
+    run<11>("ds_read2_b32 gather(32x4B, 2 rows)", d_lab);
     run<7>("ds_read_b128 gather(32x16B)", d_lab);
     run<1>("ds_read_b32 broadcast", d_lab);
     run<9>("ds_read_b32 broadcast exec=1", d_lab);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: tools/pmc_lds.sh "<K list>"  -> LDS / VALU pipe activity of the fill kernel per K
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 -L 2>/dev/null | grep -oE "SQ_[A-Z_0-9]*(LDS|VALU)[A-Z_0-9]*" | sort -u | tr '\n' ' ' > gpurun_out/pmc_lds_names.txt
+for K in $1; do
+ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"; do
+  rm -rf gpurun_out/pmcx
+  rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --cpu-sample 0 --no-check --serial --cols-per-lane $K > gpurun_out/pmcx.log 2>&1 || { tail -5 gpurun_out/pmcx.log; continue; }
+  python3 - "$K" <<'PY'
+import csv,glob,sys,collections
+f=glob.glob('gpurun_out/pmcx/*/*_counter_collection.csv')
+agg=collections.defaultdict(list); dur={}
+for r in csv.DictReader(open(f[0])):
+    if 'fill_kernel' not in r['Kernel_Name']: continue
+    agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    dur[r['Dispatch_Id']]=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
+wall=sum(dur.values())/len(dur)/1e3
+print(f"K={sys.argv[1]} fill wall {wall:.0f}us " + " ".join(f"{c}={sum(v)/len(v):.4g}" for c,v in sorted(agg.items())))
+PY
+ done
+done
