@@ -75,7 +75,7 @@ typedef struct ctcfa_plan ctcfa_plan;     /* batch geometry + device workspace  
 typedef struct ctcfa_plan_info {
     int32_t batch;
     int32_t cols_per_lane;   /* K                                   */
-    int32_t waves_per_seg;   /* W  (workgroup = 64*W threads)       */
+    int32_t waves_per_seg;   /* compute tiles (pipeline stages) per segment */
     int32_t vocab_pitch;     /* LDS row pitch in entries            */
     int32_t lds_bytes;       /* dynamic LDS of the fill kernel      */
     int32_t n_blocks_max;    /* 32-row blocks of the longest segment */

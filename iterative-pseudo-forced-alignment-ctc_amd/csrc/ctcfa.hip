@@ -47,7 +47,11 @@ struct ctcfa_plan {
     std::vector<hipEvent_t> ev;
     int ev_slots = 0;
     int64_t ev_runs = 0;
-    void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int) = nullptr;
+    void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
+                    const ctcfa::FillRoles*) = nullptr;
+    int KL = 0;                       // columns per lane of the light tiles (== K for uniform shapes)
+    ctcfa::FillRoles roles{};         // what each wave of a fill workgroup does
+    ctcfa::FillRoles* d_roles = nullptr;
 };
 
 namespace {
@@ -67,32 +71,78 @@ int set_err(ctcfa_engine* e, int code, const std::string& msg) {
             return set_err(eng, CTCFA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int);
+using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
+                        const ctcfa::FillRoles*);
 
 template <int VP>
 FillFn fill_for_k(int K) {
     switch (K) {
-        case 1: return ctcfa::fill_kernel<1, VP>;
-        case 2: return ctcfa::fill_kernel<2, VP>;
-        case 3: return ctcfa::fill_kernel<3, VP>;
-        case 4: return ctcfa::fill_kernel<4, VP>;
-        case 5: return ctcfa::fill_kernel<5, VP>;
-        case 6: return ctcfa::fill_kernel<6, VP>;
-        case 8: return ctcfa::fill_kernel<8, VP>;
-        case 10: return ctcfa::fill_kernel<10, VP>;
-        case 12: return ctcfa::fill_kernel<12, VP>;
-        case 16: return ctcfa::fill_kernel<16, VP>;
+        case 1: return ctcfa::fill_kernel<1, 1, VP>;
+        case 2: return ctcfa::fill_kernel<2, 2, VP>;
+        case 3: return ctcfa::fill_kernel<3, 3, VP>;
+        case 4: return ctcfa::fill_kernel<4, 4, VP>;
+        case 5: return ctcfa::fill_kernel<5, 5, VP>;
+        case 6: return ctcfa::fill_kernel<6, 6, VP>;
+        case 8: return ctcfa::fill_kernel<8, 8, VP>;
+        case 10: return ctcfa::fill_kernel<10, 10, VP>;
+        case 12: return ctcfa::fill_kernel<12, 12, VP>;
+        case 16: return ctcfa::fill_kernel<16, 16, VP>;
         default: return nullptr;
     }
 }
 
-FillFn select_fill(int K, int VP) {
-    switch (VP) {
-        case 32: return fill_for_k<32>(K);
-        case 64: return fill_for_k<64>(K);
-        case 128: return fill_for_k<128>(K);
+template <int VP>
+FillFn fill_mixed(int KH) {
+    switch (KH) {
+        case 2: return ctcfa::fill_kernel<2, 1, VP>;
+        case 4: return ctcfa::fill_kernel<4, 2, VP>;
         default: return nullptr;
     }
+}
+
+// KL == KH: uniform tiles; KL == KH / 2: the mixed 8-wave shape
+FillFn select_fill(int KH, int KL, int VP) {
+    if (KL == KH) {
+        switch (VP) {
+            case 32: return fill_for_k<32>(KH);
+            case 64: return fill_for_k<64>(KH);
+            case 128: return fill_for_k<128>(KH);
+            default: return nullptr;
+        }
+    }
+    switch (VP) {
+        case 32: return fill_mixed<32>(KH);
+        case 64: return fill_mixed<64>(KH);
+        case 128: return fill_mixed<128>(KH);
+        default: return nullptr;
+    }
+}
+
+// Role tables.  Uniform: waves 0..W-1 = stages 0..W-1, wave W = producer.
+ctcfa::FillRoles uniform_roles(int K, int W) {
+    ctcfa::FillRoles r{};
+    r.nwaves = W + 1;
+    r.nstages = W;
+    r.cpad = 64 * K * W;
+    for (int w = 0; w < W; ++w) r.wave[w] = {ctcfa::kRoleHeavy, (int8_t)w, (int16_t)(w * 64 * K)};
+    r.wave[W] = {ctcfa::kRoleProducer, 0, 0};
+    return r;
+}
+
+// Mixed, 8 waves: 4 heavy tiles (KH) then 2 light ones (KL), same 320*KH columns as five
+// uniform tiles.  Waves {w, w+4} share a SIMD; the pairs are (H,H), (L,producer), (H,H), (L,idle).
+ctcfa::FillRoles mixed8_roles(int KH, int KL) {
+    ctcfa::FillRoles r{};
+    r.nwaves = 8;
+    r.nstages = 6;
+    r.cpad = 64 * (4 * KH + 2 * KL);
+    const int heavy_wave[4] = {0, 2, 4, 6};  // stage 0 with stage 2 on one SIMD, 1 with 3 on another
+    for (int i = 0; i < 4; ++i) r.wave[heavy_wave[i]] = {ctcfa::kRoleHeavy, (int8_t)i, (int16_t)(i * 64 * KH)};
+    r.wave[1] = {ctcfa::kRoleLight, 4, (int16_t)(256 * KH)};
+    r.wave[3] = {ctcfa::kRoleLight, 5, (int16_t)(256 * KH + 64 * KL)};
+    r.wave[5] = {ctcfa::kRoleProducer, 0, 0};
+    r.wave[7] = {ctcfa::kRoleIdle, 0, 0};
+    return r;
 }
 
 const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
@@ -199,6 +249,7 @@ const char* ctcfa_last_error(const ctcfa_engine* eng) { return eng ? eng->err.c_
 void ctcfa_plan_destroy(ctcfa_plan* plan) {
     if (!plan) return;
     if (plan->d_segs) (void)hipFree(plan->d_segs);
+    if (plan->d_roles) (void)hipFree(plan->d_roles);
     for (int q = 0; q < 2; ++q) {
         if (plan->d_bits[q]) (void)hipFree(plan->d_bits[q]);
         if (plan->d_lastcol[q]) (void)hipFree(plan->d_lastcol[q]);
@@ -247,14 +298,38 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }
-    pl->fill_fn = select_fill(pl->K, pl->VP);
+    // Five equal tiles put 3 compute waves on two SIMDs of a CU and 2 on the others; the mixed
+    // 8-wave shape covers the same 320*K columns with 2 heavy + 1 light tile on every SIMD.
+    // Taken when the caller did not force a tile width and there are workgroups to pair up.
+    pl->KL = pl->K;
+    if (force_k == 0 && pl->W == 5 && (pl->K == 2 || pl->K == 4) && batch >= eng->num_cu &&
+        !std::getenv("CTCFA_NO_MIXED") && lds_bytes_fill(6, pl->VP) * 2 <= eng->lds_limit) {
+        pl->KL = pl->K / 2;
+        pl->roles = mixed8_roles(pl->K, pl->KL);
+    } else {
+        pl->roles = uniform_roles(pl->K, pl->W);
+    }
+    pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP);
     if (!pl->fill_fn) {
         delete pl;
         return set_err(eng, CTCFA_ERR_INVALID, "unsupported cols_per_lane");
     }
-    const int K = pl->K, W = pl->W;
-    const int64_t Cpad = 64LL * K * W;
-    pl->lds_fill = lds_bytes_fill(W, pl->VP);
+    const int K = pl->K;
+    const int64_t Cpad = pl->roles.cpad;
+    pl->lds_fill = lds_bytes_fill(pl->roles.nstages, pl->VP);
+    // tile that holds padded column pc
+    auto tile_of = [&](int pc, int* tk, int* tbase, int* tstage) {
+        for (int w = 0; w < pl->roles.nwaves; ++w) {
+            const ctcfa::WaveRole& r = pl->roles.wave[w];
+            if (r.role != ctcfa::kRoleHeavy && r.role != ctcfa::kRoleLight) continue;
+            const int k = r.role == ctcfa::kRoleHeavy ? pl->K : pl->KL;
+            if (pc >= r.cbase && pc < r.cbase + 64 * k) {
+                *tk = k; *tbase = r.cbase; *tstage = r.stage;
+                return true;
+            }
+        }
+        return false;
+    };
     pl->segs.resize(batch);
     int64_t lpz_off = 0, lab_off = 0, frm_off = 0, utt_off = 0, bits_off = 0;
     for (int b = 0; b < batch; ++b) {
@@ -267,7 +342,13 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         s.T = T[b];
         s.C = C[b];
         s.U = U ? U[b] : 0;
-        s.shift = (K - 1) - ((C[b] - 1) % K);
+        {   // left padding: the last label column must sit at k == K-1 of its lane
+            int tk = K, tbase = 0, tstage = 0;
+            (void)tile_of(C[b] - 1, &tk, &tbase, &tstage);
+            s.shift = (tk - 1) - ((C[b] - 1 - tbase) % tk);   // stays inside the same lane, hence the same tile
+            s.owner_stage = tstage;
+            s.owner_lane = (C[b] - 1 + s.shift - tbase) / tk;
+        }
         s.seg_index = b;
         s.prestatus = CTCFA_ST_OK;
         if (C[b] > T[b]) s.prestatus = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
@@ -302,6 +383,8 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
             return set_err(eng, _e == hipErrorOutOfMemory ? CTCFA_ERR_NOMEM : CTCFA_ERR_HIP, m); \
         }                                                                                     \
     } while (0)
+    PLAN_TRY(hipMalloc(&pl->d_roles, sizeof(ctcfa::FillRoles)));
+    PLAN_TRY(hipMemcpy(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice));
     PLAN_TRY(hipMalloc(&pl->d_segs, sizeof(SegDesc) * (size_t)batch));
     PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
     PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
@@ -321,7 +404,7 @@ int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
     if (!pl || !info) return CTCFA_ERR_INVALID;
     info->batch = pl->B;
     info->cols_per_lane = pl->K;
-    info->waves_per_seg = pl->W;
+    info->waves_per_seg = pl->roles.nstages;
     info->vocab_pitch = pl->VP + ctcfa::kPitchPad;
     info->lds_bytes = pl->lds_fill;
     info->n_blocks_max = pl->nblk_max;
@@ -366,9 +449,9 @@ int check_args(ctcfa_plan* pl, const RunArgs& a, bool* want_seg) {
 }
 
 int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st) {
-    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * (pl->W + 1)), pl->lds_fill, st, pl->d_segs, a.d_lpz,
+    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, pl->d_segs, a.d_lpz,
                        a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
-                       (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0);
+                       (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0, pl->d_roles);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }
@@ -377,7 +460,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     BtParams bp;
     bp.V = pl->V;
     bp.blank = pl->prm.blank;
-    bp.Cpad = 64 * pl->K * pl->W;
+    bp.Cpad = pl->roles.cpad;
     bp.flags = pl->prm.flags;
     bp.L = pl->prm.score_min_mean_over_L;
     bp.rec_bytes = pl->rec_bytes;

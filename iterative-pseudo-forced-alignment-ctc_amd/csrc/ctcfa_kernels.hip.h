@@ -29,6 +29,7 @@
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
 #endif
 #include <stdint.h>
+#include <type_traits>
 
 namespace ctcfa {
 
@@ -50,6 +51,25 @@ struct SegDesc {
     int32_t shift;      // left padding so that column C-1 lands on k == K-1
     int32_t prestatus;  // 0, or the status decided from shapes alone
     int32_t seg_index;
+    int32_t owner_stage;  // pipeline stage (tile) that holds the last label column C-1
+    int32_t owner_lane;   // ... and the lane inside it (the column sits at k == K-1 there)
+};
+
+// Launch shape of the fill kernel: what each wave of a workgroup does.  Tiles ("stages") are
+// numbered left to right; stage l works one 32-row block behind stage l-1.  A heavy tile has
+// 64*KH columns, a light one 64*KL.
+enum : int8_t { kRoleIdle = 0, kRoleProducer = 1, kRoleHeavy = 2, kRoleLight = 3 };
+struct WaveRole {
+    int8_t role;
+    int8_t stage;
+    int16_t cbase;   // first padded column of the tile
+};
+struct FillRoles {
+    int32_t nwaves;   // waves per workgroup (blockDim.x / 64)
+    int32_t nstages;  // compute tiles
+    int32_t cpad;     // padded columns = sum of tile widths (row pitch of the decision words)
+    int32_t reserved;
+    WaveRole wave[16];
 };
 
 __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) {
@@ -71,28 +91,38 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Fill kernel.  grid = B workgroups (one per segment), block = 64*(W+1) threads:
-//   waves 0..W-1  compute waves, wave w owns padded columns [w*64K, (w+1)*64K)
-//   wave  W       producer: stages emission rows global -> (e, m) pairs in the LDS ring
+// Fill kernel.  grid = B workgroups (one per segment), block = 64*nwaves threads; the role
+// table says which wave computes which tile ("stage"), which one is the producer (stages
+// emission rows global -> (e, m) pairs in the LDS ring) and which ones leave at once.
+// Uniform shapes: waves 0..W-1 are stages 0..W-1 with K columns per lane, wave W the producer.
+// Mixed shape (KH, KL), 8 waves: a workgroup of 8 waves lands as {w, w+4} pairs on the four
+// SIMDs and the neighbour workgroup on the same CU is rotated by one SIMD, so giving pairs
+// (heavy, heavy), (light, producer), (heavy, heavy), (light, idle) puts exactly
+// 2 heavy + 1 light tile on every SIMD (measured with tools/hwid_probe.hip): a step costs what
+// the most loaded SIMD issues, and 5 equal tiles per workgroup would put 3 on two SIMDs and 2
+// on the others.
 // Roles never mix: compute waves issue only global STORES (decision words, last-column
 // scores) and never wait on vmcnt; the producer issues only LOADS.  (vmcnt retires in issue
 // order on gfx9, so one wave doing both pays an HBM write round trip in every load wait.)
 // dynamic LDS = (W+1) slots * kRows * (VP+1) * 8  +  boundary columns  +  small buffers.
 // ---------------------------------------------------------------------------------------
-template <int K, int VP>
-__global__ void __launch_bounds__((K >= 10) ? 320 : 1024)
+template <int KH, int KL, int VP>
+__global__ void __launch_bounds__((KH >= 10) ? 320 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
-            float* __restrict__ lastcol, int V, int blank, int preamble) {
+            float* __restrict__ lastcol, int V, int blank, int preamble,
+            const FillRoles* __restrict__ roles) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int PITCH = VP + kPitchPad;  // row pitch in (e, m) entries; entry VP = start-column pseudo label
     constexpr int SLOT_BYTES = kRows * PITCH * 8;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = (blockDim.x >> 6) - 1;  // compute waves
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WaveRole my = roles->wave[wave_id];
+    const int W = roles->nstages;         // compute tiles == pipeline stages
     const int NS = W + 1;                 // ring slots: W blocks being read + 1 being written
+    const int w = my.stage;               // this wave's stage (compute waves)
 
     const SegDesc sd = segs[blockIdx.x];
     if (sd.prestatus != 0) return;  // uniform: nothing to fill
@@ -113,13 +143,14 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     volatile int* posflag = reinterpret_cast<volatile int*>(smem + sink_base + kSinkBytes);
     float* bnd = reinterpret_cast<float*>(smem + bnd_base);
     const int nblk = (T - 1 + kRows - 1) / kRows;
-    const int Cpad = 64 * K * W;
+    const int Cpad = roles->cpad;
     const int nsteps = nblk + W - 1;
 
     for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = kProbMax;
     if (tid == 0) *posflag = 0;
 
-    if (w == W) {
+    if (my.role == kRoleIdle) return;  // a finished wave no longer counts at s_barrier
+    if (my.role == kRoleProducer) {
         // ============================ producer wave ===========================================
         // Block jb = rows t in [32*jb + 1, 32*jb + 32].  One pass of the wave covers 64/VP rows
         // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
@@ -272,12 +303,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     }
 
     // ================================ compute waves ===========================================
+    auto compute = [&](auto ktag) {
+    constexpr int K = decltype(ktag)::value;
+    const int cbase = my.cbase;
     float prev[K];
     uint32_t dec[K];
     uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair in row 0 of the current slot
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int pc = (w * 64 + lane) * K + k;
+        const int pc = cbase + lane * K + k;
         const int c = pc - shift;
         int lab;
         if (c <= 0) lab = VP;                  // start column / left padding
@@ -287,9 +321,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         prev[k] = (c <= 0) ? 0.0f : kProbMax;  // table[0,0] = 0, table[0,c>0] = -1e9
         dec[k] = 0u;
     }
-    const int pcl = C - 1 + shift;  // padded index of the last label column
-    const int wstar = pcl / (64 * K);        // wave that owns the last label column (ragged batches: <= W-1)
-    const int lstar = (pcl % (64 * K)) / K;
+    const int wstar = sd.owner_stage;  // stage that owns the last label column (ragged batches: <= W-1)
+    const int lstar = sd.owner_lane;
     float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);  // .x = row 0 of every label column
 
     lds_barrier();  // block 0 staged, boundary columns initialised
@@ -307,7 +340,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // are alive, or compute dead cells from stale-but-finite ring entries).
     int jlast = nblk - 1;
     {
-        const int cmax = ((w + 1) * 64 * K - 1) - shift;   // right-most column of this wave
+        const int cmax = (cbase + 64 * K - 1) - shift;     // right-most column of this wave
         if (cmax < C - 1) {
             const int tdead = T - C + cmax;                // last row where cmax is alive
             jlast = tdead >= 1 ? (tdead - 1) / kRows : -1;
@@ -321,7 +354,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // starts from the state it would have computed: -1e9 in every column, -1e9 boundary rows.
     int jfirst = 0;
     {
-        const int cmin = w * 64 * K - shift;               // left-most column of this wave
+        const int cmin = cbase - shift;                    // left-most column of this wave
         if (cmin >= 1) jfirst = (cmin - 1) / kRows;
         if (jfirst > jlast + 1) jfirst = jlast + 1;
     }
@@ -422,7 +455,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 for (int k = 0; k < K; ++k) asm volatile("" : "+v"(dec[k]));
             }
             // decision words of this block (fire and forget: this wave never waits on vmcnt)
-            uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + (w * 64 + lane) * K;
+            uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) bp[k] = dec[k];
             if (w == wstar) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
@@ -435,6 +468,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     }
     // row 32*nblk (present when (T-1) % 32 == 0) is still in pub4.x
     if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;
+    };  // compute
+    if (KH == KL || my.role == kRoleHeavy) compute(std::integral_constant<int, KH>{});
+    else compute(std::integral_constant<int, KL>{});
 }
 
 // ---------------------------------------------------------------------------------------

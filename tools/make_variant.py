@@ -53,6 +53,12 @@ def patch_D(k, h):
     return k, h
 
 
+def patch_G(k, h):
+    """every gather reads entry 0 of its row (pure LDS broadcast: no bank conflicts, minimum data)"""
+    k = sub(k, "gaddr[k] = static_cast<uint32_t>(lab) * 8u;", "gaddr[k] = 0u * static_cast<uint32_t>(lab);")
+    return k, h
+
+
 def patch_stamp(k, h):
     stamp_def = """
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(seg_lastcol);
@@ -93,7 +99,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
