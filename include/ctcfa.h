@@ -50,7 +50,7 @@ extern "C" {
 #define CTCFA_ST_AUDIO_SHORTER_THAN_TEXT 1 /* AssertionError("Audio is shorter than text!"),
                                               caught at iterative_utterance_alignment.py:390 */
 #define CTCFA_ST_BACKTRACK_FAILED 2        /* IndexError re-raised by ctc_segmentation()      */
-#define CTCFA_ST_WINDOWED_UNSUPPORTED 3    /* T > min_window_size: DP-window regime */
+#define CTCFA_ST_WINDOWED_UNSUPPORTED 3    /* windowed regime with T*4 bytes > LDS (T > ~40 000 frames) */
 
 /* flags (CtcSegmentationParameters.flags + the backtrack switch) */
 #define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; not yet supported */

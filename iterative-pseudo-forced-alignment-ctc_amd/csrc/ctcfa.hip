@@ -49,6 +49,13 @@ struct ctcfa_plan {
     int64_t ev_runs = 0;
     void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
                     const ctcfa::FillRoles*) = nullptr;
+    // windowed regime (T > min_window_size): segment indices, fp32 table + per-column offsets
+    std::vector<int32_t> win_list;
+    int32_t* d_win_list = nullptr;
+    float* d_win_table = nullptr;
+    int32_t* d_win_offs = nullptr;
+    int64_t win_table_floats = 0, win_cols = 0;
+    int lds_win = 0;
     int KL = 0;                       // columns per lane of the light tiles (== K for uniform shapes)
     ctcfa::FillRoles roles{};         // what each wave of a fill workgroup does
     ctcfa::FillRoles* d_roles = nullptr;
@@ -195,7 +202,7 @@ const char* ctcfa_status_string(int s) {
         case CTCFA_ST_OK: return "ok";
         case CTCFA_ST_AUDIO_SHORTER_THAN_TEXT: return "Audio is shorter than text!";
         case CTCFA_ST_BACKTRACK_FAILED: return "backtrack left the trellis (IndexError in ctc_segmentation)";
-        case CTCFA_ST_WINDOWED_UNSUPPORTED: return "T > min_window_size: windowed DP regime not supported";
+        case CTCFA_ST_WINDOWED_UNSUPPORTED: return "windowed DP regime (T > min_window_size) with T beyond the LDS column buffer (~40 000 frames)";
         default: return "unknown status";
     }
 }
@@ -250,6 +257,9 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
     if (!plan) return;
     if (plan->d_segs) (void)hipFree(plan->d_segs);
     if (plan->d_roles) (void)hipFree(plan->d_roles);
+    if (plan->d_win_list) (void)hipFree(plan->d_win_list);
+    if (plan->d_win_table) (void)hipFree(plan->d_win_table);
+    if (plan->d_win_offs) (void)hipFree(plan->d_win_offs);
     for (int q = 0; q < 2; ++q) {
         if (plan->d_bits[q]) (void)hipFree(plan->d_bits[q]);
         if (plan->d_lastcol[q]) (void)hipFree(plan->d_lastcol[q]);
@@ -352,7 +362,20 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         s.seg_index = b;
         s.prestatus = CTCFA_ST_OK;
         if (C[b] > T[b]) s.prestatus = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
-        else if (T[b] > params->min_window_size) s.prestatus = CTCFA_ST_WINDOWED_UNSUPPORTED;
+        else if (T[b] > params->min_window_size) {
+            // windowed regime: own kernel, needs T floats of LDS and a T x C fp32 table in HBM
+            if ((int64_t)T[b] * 4 > (int64_t)eng->lds_limit) {
+                s.prestatus = CTCFA_ST_WINDOWED_UNSUPPORTED;
+            } else {
+                s.prestatus = ctcfa::kPreWindowed;
+                s.win_off = pl->win_table_floats;
+                s.wcol_off = pl->win_cols;
+                pl->win_table_floats += (int64_t)T[b] * C[b];
+                pl->win_cols += C[b];
+                pl->lds_win = std::max(pl->lds_win, (int)T[b] * 4);
+                pl->win_list.push_back(b);
+            }
+        }
         const int nblk = (T[b] - 1 + ctcfa::kRows - 1) / ctcfa::kRows;
         pl->nblk_max = std::max(pl->nblk_max, nblk);
         lpz_off += (int64_t)T[b] * vocab;
@@ -368,7 +391,12 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     pl->total_U = utt_off;
     pl->bits_words = bits_off;
     pl->rec_bytes = (std::max(1, pl->nblk_max) * 8 + 15) / 16 * 16;
-    pl->lds_bt = pl->rec_bytes + Tmax * 4;
+    {   // the backtrack kernel keeps char_probs of its segment in LDS; windowed segments have their own kernel
+        int Tbt = 1;
+        for (int b = 0; b < batch; ++b)
+            if (pl->segs[b].prestatus == CTCFA_ST_OK) Tbt = std::max(Tbt, (int)T[b]);
+        pl->lds_bt = pl->rec_bytes + Tbt * 4;
+    }
     if (pl->lds_bt > eng->lds_limit) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "segment too long for the backtrack record buffer");
@@ -395,6 +423,16 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     if (pl->lds_bt > 48 * 1024)
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ctcfa::backtrack_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
+    if (!pl->win_list.empty()) {
+        PLAN_TRY(hipMalloc(&pl->d_win_list, sizeof(int32_t) * pl->win_list.size()));
+        PLAN_TRY(hipMemcpy(pl->d_win_list, pl->win_list.data(), sizeof(int32_t) * pl->win_list.size(),
+                           hipMemcpyHostToDevice));
+        PLAN_TRY(hipMalloc(&pl->d_win_table, sizeof(float) * (size_t)pl->win_table_floats));
+        PLAN_TRY(hipMalloc(&pl->d_win_offs, sizeof(int32_t) * (size_t)pl->win_cols));
+        if (pl->lds_win > 48 * 1024)
+            PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ctcfa::windowed_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_win));
+    }
 #undef PLAN_TRY
     *out = pl;
     return CTCFA_OK;
@@ -470,6 +508,22 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
                        bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
                        want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status);
     HIP_TRY(pl->eng, hipGetLastError());
+    if (!pl->win_list.empty()) {
+        ctcfa::WinParams wp;
+        wp.V = pl->V;
+        wp.blank = pl->prm.blank;
+        wp.flags = pl->prm.flags;
+        wp.L = pl->prm.score_min_mean_over_L;
+        wp.min_window = pl->prm.min_window_size;
+        wp.max_window = pl->prm.max_window_size;
+        wp.dur = pl->prm.index_duration;
+        hipLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
+                           pl->lds_win, st, pl->d_segs, pl->d_win_list, a.d_lpz, a.d_labels,
+                           want_seg ? a.d_utt_begin : nullptr, pl->d_win_table, pl->d_win_offs, wp, a.d_fol,
+                           a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
+                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status);
+        HIP_TRY(pl->eng, hipGetLastError());
+    }
     return CTCFA_OK;
 }
 

@@ -40,6 +40,7 @@ constexpr int kSinkBytes = 1280; // sink for lanes that publish nothing (64 x 16
 constexpr int kPitchPad = 2;   // LDS row = VP + 2 entries: 16-B aligned rows, banks rotate by 4 per row
 constexpr float kProbMax = -1000000000.0f;   // Cython sentinel (prob_max)
 constexpr float kMaxProb = -10000000000.0f;  // config.max_prob on the NumPy side
+constexpr int kPreWindowed = 100;  // SegDesc.prestatus: T > min_window_size, handled by windowed_kernel
 
 struct SegDesc {
     int64_t lpz_off;   // elements into lpz
@@ -53,6 +54,8 @@ struct SegDesc {
     int32_t seg_index;
     int32_t owner_stage;  // pipeline stage (tile) that holds the last label column C-1
     int32_t owner_lane;   // ... and the lane inside it (the column sits at k == K-1 there)
+    int64_t win_off;      // windowed segments: floats into the table workspace
+    int64_t wcol_off;     // windowed segments: ints into the per-column offsets workspace
 };
 
 // Launch shape of the fill kernel: what each wave of a workgroup does.  Tiles ("stages") are
@@ -511,6 +514,64 @@ __device__ __forceinline__ double np_pairwise_sum_le128(const float* a, int n) {
     return res;
 }
 
+// determine_utterance_segments() of ctc-segmentation 1.7.1 for one segment: utterances over
+// waves, lanes = sliding windows.  `fol` = frame of every label column (read with agent-scope
+// loads: written by other waves of this workgroup), `cps` = the segment's char_probs in LDS.
+template <int NTHREADS>
+__device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, double dur, const int32_t* ub,
+                                                 const int32_t* fol, const float* cps, int T, int C, int U,
+                                                 double* __restrict__ seg_start, double* __restrict__ seg_end,
+                                                 double* __restrict__ seg_score) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = NTHREADS / 64;
+    auto tim = [&](int c) {
+        if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
+        return (double)__hip_atomic_load(fol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * dur;
+    };
+    const int n = L;
+    for (int u = wave; u < U; u += NW) {
+        const int b = ub[u], e = ub[u + 1];
+        const double mid_b = (tim(b) + tim(b - 1)) / 2;
+        const double sb = tim(b + 1) - 0.5;
+        const double start = (mid_b > sb) ? mid_b : sb;  // max(timings[b+1]-0.5, middle)
+        const double mid_e = (tim(e) + tim(e - 1)) / 2;
+        const double ee = tim(e - 1) + 0.5;
+        const double end = (mid_e < ee) ? mid_e : ee;  // min(timings[e-1]+0.5, middle)
+        const long long start_t = (long long)rint(start / dur);
+        const long long end_t = (long long)rint(end / dur);
+        double min_avg;
+        if (end_t <= start_t) {
+            min_avg = -10000000000.0;
+        } else if (end_t - start_t <= n) {
+            long long lo = start_t < 0 ? 0 : start_t, hi = end_t > T ? T : end_t;
+            if (lo > T) lo = T;
+            if (hi < lo) hi = lo;
+            min_avg = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
+        } else {
+            double local = 0.0;
+            for (long long t0 = start_t + lane; t0 < end_t - n; t0 += 64) {
+                long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
+                if (lo > T) lo = T;
+                if (hi < lo) hi = lo;
+                const double m = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
+                if (m < local) local = m;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(local, off);
+                if (o < local) local = o;
+            }
+            min_avg = local;
+        }
+        if (lane == 0) {
+            seg_start[sd.utt_off + u] = start;
+            seg_end[sd.utt_off + u] = end;
+            seg_score[sd.utt_off + u] = min_avg;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBtThreads)
 backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                  const int32_t* __restrict__ labels, const int32_t* __restrict__ utt_begin,
@@ -555,6 +616,7 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             t_end_out[sd.seg_index] = -1;
         }
     };
+    if (sd.prestatus == kPreWindowed) return;  // windowed_kernel owns this segment
     if (sd.prestatus != 0) {
         fail(sd.prestatus);
         return;
@@ -709,53 +771,329 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
     __threadfence_block();
     __syncthreads();
 
-    // ---- phase C: determine_utterance_segments; utterances over waves, lanes = windows ------
-    const int32_t* ub = utt_begin + sd.utt_off + sd.seg_index;
-    auto tim = [&](int c) {
-        if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
-        return (double)__hip_atomic_load(fol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * p.dur;
-    };
-    const int n = p.L;
-    for (int u = wave; u < U; u += NW) {
-        const int b = ub[u], e = ub[u + 1];
-        const double mid_b = (tim(b) + tim(b - 1)) / 2;
-        const double sb = tim(b + 1) - 0.5;
-        const double start = (mid_b > sb) ? mid_b : sb;  // max(timings[b+1]-0.5, middle)
-        const double mid_e = (tim(e) + tim(e - 1)) / 2;
-        const double ee = tim(e - 1) + 0.5;
-        const double end = (mid_e < ee) ? mid_e : ee;  // min(timings[e-1]+0.5, middle)
-        const long long start_t = (long long)rint(start / p.dur);
-        const long long end_t = (long long)rint(end / p.dur);
-        double min_avg;
-        if (end_t <= start_t) {
-            min_avg = -10000000000.0;
-        } else if (end_t - start_t <= n) {
-            long long lo = start_t < 0 ? 0 : start_t, hi = end_t > T ? T : end_t;
-            if (lo > T) lo = T;
-            if (hi < lo) hi = lo;
-            min_avg = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
-        } else {
-            double local = 0.0;
-            for (long long t0 = start_t + lane; t0 < end_t - n; t0 += 64) {
-                long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
-                if (lo > T) lo = T;
-                if (hi < lo) hi = lo;
-                const double m = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
-                if (m < local) local = m;
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double o = __shfl_xor(local, off);
-                if (o < local) local = o;
-            }
-            min_avg = local;
-        }
-        if (lane == 0) {
-            seg_start[sd.utt_off + u] = start;
-            seg_end[sd.utt_off + u] = end;
-            seg_score[sd.utt_off + u] = min_avg;
-        }
+    // ---- phase C: determine_utterance_segments ------------------------------------------------
+    score_utterances<kBtThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,
+                                 seg_start, seg_end, seg_score);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Windowed regime (T > min_window_size): ctc-segmentation keeps only W = min(window, T) rows
+// per column; column c's window starts offsets[c] frames into the audio and the step from
+// offsets[c-1] depends on where column c-1 had its (first) maximum.  That makes the fill
+// sequential column after column, and inside a column the fp32 chain
+//     x_t = max( b_t , x_{t-1} + m_t )
+// is sequential by rounding.  One workgroup per segment; wave 0 fills: lanes = 64 consecutive
+// rows, b_t / m_t in parallel, the chain as 64 dependent (v_add_dpp wave_shr:1, v_max) pairs --
+// after k iterations lanes <= k are final.  The full fp32 table goes to HBM (column-major,
+// coalesced), exactly what the package allocates, because its backtrack reads table rows
+// through NumPy index wrap-around when a window was too small -- the walk (lane 0) restates
+// that loop literally, including the IndexError that doubles the window.  Rare path (windows
+// longer than 160 s): written for exactness, not speed.
+// dynamic LDS: T floats (previous/current column in place during the fill, char_probs after).
+// ---------------------------------------------------------------------------------------
+constexpr int kWinThreads = 256;
+
+struct WinParams {
+    int V, blank;
+    uint32_t flags;
+    int L;
+    int min_window, max_window;
+    double dur;
+};
+
+__device__ __forceinline__ int64_t np_index(int64_t i, int64_t n, int& err) {
+    if (i < 0) i += n;
+    if (i < 0 || i >= n) {
+        err = 1;
+        return 0;
     }
+    return i;
+}
+
+__global__ void __launch_bounds__(kWinThreads)
+windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ win_list,
+                const float* __restrict__ lpz, const int32_t* __restrict__ labels,
+                const int32_t* __restrict__ utt_begin, float* __restrict__ table_ws,
+                int32_t* __restrict__ offs_ws, WinParams p, int32_t* __restrict__ frame_of_label,
+                float* __restrict__ char_prob, int32_t* __restrict__ state,
+                double* __restrict__ seg_start, double* __restrict__ seg_end,
+                double* __restrict__ seg_score, int32_t* __restrict__ t_end_out,
+                int32_t* __restrict__ status_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int sh_res[2];  // [0] t_end, [1] error flag of the walk
+    float* col = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SegDesc sd = segs[win_list[blockIdx.x]];
+    const int T = sd.T, C = sd.C, U = sd.U, V = p.V;
+    const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    int32_t* fol = frame_of_label + sd.lab_off;
+    float* cp = char_prob + sd.frm_off;
+    int32_t* st = state ? state + sd.frm_off : nullptr;
+    float* table = table_ws + sd.win_off;      // column-major: table[c * W + t]
+    int32_t* offsets = offs_ws + sd.wcol_off;  // [C]
+    const bool want_seg = (utt_begin != nullptr) && (seg_score != nullptr) && U > 0;
+    const bool preamble = (p.flags & 2u) != 0u;
+    const float pm = kProbMax;
+
+    long long window = p.min_window;
+    int status = 0;
+    int t_end = 0;
+    for (;;) {
+        const int W = (int)(window < (long long)T ? window : (long long)T);
+        // outputs start from the package's initial state on every attempt
+        for (int c = tid; c < C; c += kWinThreads) fol[c] = 0;
+        for (int t = tid; t < T; t += kWinThreads) {
+            cp[t] = 0.0f;
+            if (st) st[t] = -2;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // ------------------------------- fill ------------------------------------------
+            const float mean_offset = (float)((double)(T - W) / (double)C);
+            const int higher_offset = (int)mean_offset + 1;
+            int offset_sum = 0, last_arg = -1;
+            const int nchunk = (W + 63) / 64;
+            for (int c = 0; c < C; ++c) {
+                int off = 0;
+                if (c > 0) {
+                    int a = last_arg - W / 2;
+                    if (a < 0) a = 0;
+                    int b = (T - W) - offset_sum;
+                    if (higher_offset < b) b = higher_offset;
+                    off = a < b ? a : b;
+                    offset_sum += off;
+                }
+                if (lane == 0) __hip_atomic_store(offsets + c, offset_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int g = seg_lab[c];  // -1 for c == 0
+                float best_v = 0.0f;
+                int best_t = -1;
+                float carry = 0.0f;  // x of the row before this chunk
+                // previous column's value for the switch candidate of row t: col[t - 1 + off]
+                auto load_prev = [&](int t0) -> float {
+                    const int t = t0 + lane;
+                    const int r = t - 1 + off;
+                    return (c > 0 && t < W && r >= 0 && r < W) ? col[r] : pm;
+                };
+                float pin = load_prev(0);
+                float* tcol = table + (int64_t)c * W;
+                // emissions of the next chunk are requested before this chunk's chain (HBM/L2 latency
+                // would otherwise sit in front of every 64-row chain)
+                auto load_em = [&](int t0, float& e_out, float& lb_out) {
+                    const int t = t0 + lane;
+                    const int f = (t < W) ? t + offset_sum : T - 1;
+                    lb_out = seg_lpz[(int64_t)f * V + p.blank];
+                    e_out = (c > 0) ? seg_lpz[(int64_t)f * V + g] : 0.0f;
+                };
+                float e_cur, lb_cur;
+                load_em(0, e_cur, lb_cur);
+                for (int ch = 0; ch < nchunk; ++ch) {
+                    const int t0 = ch * 64;
+                    const int t = t0 + lane;
+                    const bool valid = t < W;
+                    const float pin_next = load_prev(t0 + 64);  // read before this chunk overwrites col[]
+                    float e_next, lb_next;
+                    load_em(t0 + 64, e_next, lb_next);
+                    const float lb = lb_cur;
+                    float b, m;
+                    if (c > 0) {
+                        const float e = e_cur;
+                        const int r = t - 1 + off;
+                        const float pcand = (r >= W || r < 0) ? pm : pin + e;
+                        b = pcand > pm ? pcand : pm;           // switch_prob = max(prob_max, p)
+                        const float mlpz = e > pm ? e : pm;    // max_lpz_prob
+                        m = mlpz > lb ? mlpz : lb;             // max(lpz[blank], max_lpz_prob)
+                    } else {
+                        b = (t == 0) ? 0.0f : pm;              // table[0,0] = 0; no switch into column 0
+                        m = preamble ? 0.0f : (pm > lb ? pm : lb);
+                    }
+                    // chain: lane i <- max(b_i, x_{i-1} + m_i).  Row 0 has no stay candidate: m = -inf
+                    // there makes the sum lose against b >= -1e9.  Two VALU per step: the add reads
+                    // lane i-1 through DPP (lane 0 has no source lane and keeps carry + m_0).
+                    if (t == 0) m = -__builtin_inff();
+                    float tmp = carry + m;
+                    float x = __builtin_fmaxf(tmp, b);
+#pragma unroll 9
+                    for (int it = 0; it < 63; ++it) {
+                        // s_nop 1: a DPP operand written by the previous VALU needs two wait states,
+                        // and the hazard recogniser does not look inside inline asm
+                        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(tmp) : "v"(x), "v"(m));
+                        x = __builtin_fmaxf(tmp, b);
+                    }
+                    if (valid) {
+                        col[t] = x;
+                        tcol[t] = x;
+                    }
+                    // first maximum of the column (rows t >= 1 for column 0), strict '<' to replace
+                    {
+                        const bool counted = valid && !(c == 0 && t == 0);
+                        float cm = counted ? x : -__builtin_inff();
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) {
+                            const float ov = __shfl_xor(cm, o);
+                            cm = ov > cm ? ov : cm;
+                        }
+                        const unsigned long long eq = __builtin_amdgcn_ballot_w64(counted && x == cm);
+                        if (eq != 0ull) {
+                            const int fl = __builtin_ctzll(eq);
+                            if (best_t == -1 || best_v < cm) {
+                                best_v = cm;
+                                best_t = t0 + fl;
+                            }
+                        }
+                    }
+                    const int lastl = (W - 1 - t0) < 63 ? (W - 1 - t0) : 63;
+                    carry = __shfl(x, lastl);
+                    pin = pin_next;
+                    e_cur = e_next;
+                    lb_cur = lb_next;
+                }
+                last_arg = best_t;
+            }
+            __threadfence();
+            // ------------------------------- walk (lane 0) ---------------------------------
+            int err = 0;
+            int te = (p.flags & 4u) ? W - 1 : last_arg;
+            if (lane == 0) {
+                auto tab = [&](int64_t r, int64_t cc) -> float {
+                    return __hip_atomic_load(table + cc * W + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                auto offs = [&](int64_t cc) -> int64_t {
+                    return (int64_t)__hip_atomic_load(offsets + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                const double max_prob = -10000000000.0;
+                int64_t t = te, c = C - 1, offset = 0;
+                while ((t != 0 || c != 0) && !err) {
+                    int min_s = -1;
+                    double min_delta = __builtin_inf();
+                    double max_lpz = max_prob;
+                    bool max_lpz_f32 = false;
+                    const int64_t cw = np_index(c, C, err);
+                    if (err) break;
+                    const int g = seg_lab[cw];
+                    if (g != -1) {
+                        const int64_t pc = np_index(c - 1, C, err);
+                        if (err) break;
+                        offset = offs(cw) - ((c > 0) ? offs(pc) : 0);
+                        double sp;
+                        bool sp_f32 = false;
+                        if (c > 0) {
+                            const int64_t r = np_index(t + offs(cw), T, err);
+                            const int64_t gi = np_index(g, V, err);
+                            if (err) break;
+                            sp = (double)seg_lpz[r * V + gi];
+                            sp_f32 = true;
+                        } else {
+                            sp = max_prob;
+                        }
+                        const int64_t r0 = np_index(t, W, err);
+                        const int64_t r1 = np_index(t - 1 + offset, W, err);
+                        if (err) break;
+                        const float est32 = tab(r0, cw) - tab(r1, pc);
+                        double delta;
+                        if (sp_f32) delta = (double)__builtin_fabsf((float)sp - est32);
+                        else delta = __builtin_fabs(sp - (double)est32);
+                        if (delta < min_delta) {
+                            min_delta = delta;
+                            min_s = 0;
+                        }
+                        if (sp > max_lpz) {
+                            max_lpz = sp;
+                            max_lpz_f32 = sp_f32;
+                        }
+                    }
+                    double stay;
+                    bool stay_f32 = false;
+                    if (t > 0) {
+                        const int64_t r = np_index(t + offs(cw), T, err);
+                        if (err) break;
+                        const double lb = (double)seg_lpz[r * V + p.blank];
+                        if (max_lpz > lb) {
+                            stay = max_lpz;
+                            stay_f32 = max_lpz_f32;
+                        } else {
+                            stay = lb;
+                            stay_f32 = true;
+                        }
+                    } else {
+                        stay = max_prob;
+                    }
+                    const int64_t r0 = np_index(t, W, err);
+                    const int64_t r1 = np_index(t - 1, W, err);
+                    if (err) break;
+                    const float est_stay32 = tab(r0, cw) - tab(r1, cw);
+                    double stay_delta;
+                    if (stay_f32) stay_delta = (double)__builtin_fabsf((float)stay - est_stay32);
+                    else stay_delta = __builtin_fabs(stay - (double)est_stay32);
+                    if (stay_delta > min_delta) {
+                        if (c > 0) {
+                            const int64_t fr = np_index(offs(cw) + t, T, err);
+                            if (err) break;
+                            const int64_t ci = np_index(c, C, err);  // s = 0 .. min_s with min_s == 0
+                            if (err) break;
+                            fol[ci] = (int32_t)(offs(cw) + t);
+                            cp[fr] = (float)max_lpz;
+                            if (st) st[fr] = g;
+                        }
+                        c -= 1 + min_s;
+                        t -= 1 - offset;
+                    } else {
+                        const int64_t fr = np_index(offs(cw) + t, T, err);
+                        if (err) break;
+                        cp[fr] = (float)stay;
+                        if (st) st[fr] = -1;
+                        t -= 1;
+                    }
+                }
+                sh_res[0] = te;
+                sh_res[1] = err;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        t_end = sh_res[0];
+        const int err = sh_res[1];
+        __syncthreads();
+        if (!err) break;
+        window *= 2;
+        if (window < (long long)p.max_window) continue;
+        status = 2;  // the package re-raises the IndexError
+        break;
+    }
+
+    if (status != 0) {
+        for (int c = tid; c < C; c += kWinThreads) fol[c] = 0;
+        for (int t = tid; t < T; t += kWinThreads) {
+            cp[t] = 0.0f;
+            if (st) st[t] = -2;
+        }
+        if (want_seg)
+            for (int u = tid; u < U; u += kWinThreads) {
+                seg_start[sd.utt_off + u] = 0.0;
+                seg_end[sd.utt_off + u] = 0.0;
+                seg_score[sd.utt_off + u] = 0.0;
+            }
+        if (tid == 0) {
+            status_out[sd.seg_index] = status;
+            t_end_out[sd.seg_index] = -1;
+        }
+        return;
+    }
+    if (tid == 0) {
+        status_out[sd.seg_index] = 0;
+        t_end_out[sd.seg_index] = t_end;
+    }
+    if (!want_seg) return;
+    // char_probs of this segment into LDS (the column buffer is free now)
+    for (int t = tid; t < T; t += kWinThreads)
+        col[t] = __hip_atomic_load(cp + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    score_utterances<kWinThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, col, T, C, U,
+                                  seg_start, seg_end, seg_score);
 }
 
 }  // namespace ctcfa

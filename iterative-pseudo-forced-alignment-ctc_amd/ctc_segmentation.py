@@ -182,7 +182,7 @@ def _raise_for_status(status):
     if status == _native.ST_BACKTRACK_FAILED:
         raise IndexError("CTC segmentation backtrack left the trellis")
     if status == _native.ST_WINDOWED_UNSUPPORTED:
-        raise NotImplementedError("lpz longer than min_window_size: windowed DP regime not supported")
+        raise NotImplementedError("windowed DP regime with more than ~40 000 frames (one column must fit the LDS)")
     if status != _native.ST_OK:
         raise RuntimeError(f"ctcfa status {status}")
 

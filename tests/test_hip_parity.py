@@ -404,3 +404,85 @@ def test_emissions_that_are_not_log_probabilities(pkg, oracle, where):
             lpz[40 + 13 * s, 5] = np.float32(3.25)
         segs.append((lpz, gt, ub))
     _check(pkg, oracle, segs, _run(pkg, segs))
+
+
+# ---- windowed regime: T > min_window_size -------------------------------------
+def _windowed_cases():
+    cases = []
+    for s, (T, U, n, mw) in enumerate([(400, 6, 12, 80), (700, 9, 15, 128), (1000, 12, 14, 100),
+                                       (333, 3, 20, 64), (900, 20, 9, 256), (520, 4, 30, 500)]):
+        cases.append((1700 + s, T, U, n, mw))
+    return cases
+
+
+@pytest.mark.parametrize("max_window", [1000, 300])
+def test_windowed_regime_matches_oracle(pkg, oracle, max_window):
+    """Small min_window_size so that the per-column window offsets, window doubling after a
+    failed backtrack and the final IndexError (max_window=300) all occur at test sizes."""
+    seen_status = set()
+    for seed, T, U, n, mw in _windowed_cases():
+        seg = pkg.synthetic.make_segment(seed, T, 32, U, n)
+        kw = dict(min_window_size=mw, max_window_size=max_window)
+        res = _run(pkg, [seg], **kw)
+        _check(pkg, oracle, [seg], res, cfg_kw=kw)
+        seen_status.add(int(res[0]["status"]))
+    assert 0 in seen_status
+
+
+def test_windowed_and_plain_segments_in_one_batch(pkg, oracle):
+    """A batch that mixes both regimes: T <= min_window_size goes through fill + backtrack,
+    T > min_window_size through the windowed kernel; results land in the same arrays."""
+    mw = 300
+    segs = [pkg.synthetic.make_segment(1800 + s, T, 32, U, n)
+            for s, (T, U, n) in enumerate([(250, 4, 12), (900, 10, 14), (300, 5, 10), (301, 5, 10), (1500, 12, 20)])]
+    kw = dict(min_window_size=mw, max_window_size=4000)
+    _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+
+
+def test_windowed_regime_noisy_and_flat_emissions(pkg, oracle):
+    """Emissions without a planted path: the window offsets follow the noise, backtracks fail
+    and windows double more often."""
+    segs = []
+    for s in range(4):
+        rng = np.random.default_rng(1900 + s)
+        gt, ub = pkg.synthetic.make_labels(rng, 5 + s, 10, 32)
+        T = 500 + 120 * s
+        lpz = np.log(rng.dirichlet(np.ones(32) * (0.3 if s % 2 else 5.0), size=T)).astype(np.float32)
+        segs.append((lpz, gt, ub))
+    for mw, mx in ((64, 2000), (100, 400)):
+        kw = dict(min_window_size=mw, max_window_size=mx)
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+
+
+def test_windowed_regime_production_window(pkg, oracle):
+    """The package defaults (min_window_size=8000): a 190 s window, T = 9500 frames."""
+    seg = pkg.synthetic.make_segment(1950, 9500, 32, 40, 30)
+    _check(pkg, oracle, [seg], _run(pkg, [seg]))
+
+
+@pytest.mark.parametrize("mw", [8, 12, 16, 24])
+def test_windowed_regime_failed_backtracks_and_window_doubling(pkg, oracle, mw):
+    """Peaky random emissions and tiny windows: about one backtrack in five leaves the table
+    (the package's IndexError), the window doubles once or twice, or -- with max_window_size
+    just above the first window -- the error is final (status 2).  ~100 segments per launch."""
+    segs = []
+    for seed in range(4000, 4400):
+        rng = np.random.default_rng(seed)
+        U = int(rng.integers(2, 10))
+        n = int(rng.integers(4, 12))
+        gt, ub = pkg.synthetic.make_labels(rng, U, n, 32)
+        T = int(len(gt) * rng.uniform(1.2, 8))
+        w = int(rng.choice([8, 12, 16, 24]))
+        alpha = float(rng.choice([0.02, 0.05, 0.1]))
+        if w != mw or T <= w:
+            continue
+        lpz = np.log(rng.dirichlet(np.ones(32) * alpha, size=T) + 1e-30).astype(np.float32)
+        segs.append((lpz, gt, ub))
+    assert len(segs) > 50
+    n_fail = {}
+    for mx in (mw + 1, 2 * mw + 1, 100000):
+        kw = dict(min_window_size=mw, max_window_size=mx)
+        res = _run(pkg, segs, **kw)
+        _check(pkg, oracle, segs, res, cfg_kw=kw)
+        n_fail[mx] = sum(int(r["status"]) == 2 for r in res)
+    assert n_fail[mw + 1] >= 3 and n_fail[100000] == 0 and n_fail[2 * mw + 1] < n_fail[mw + 1]
