@@ -31,6 +31,12 @@ except Exception:  # pragma: no cover
     torch = None
 
 
+def wav2vec2_frames(n_samples):
+    """Frames the wav2vec2 / HuBERT convolutional front end yields for n samples (receptive
+    field 400, hop 320): the ``frames_fn`` of ``CTCSegmentation.get_lpz_batch``."""
+    return (int(n_samples) - 400) // 320 + 1
+
+
 class CTCSegmentationTask(SimpleNamespace):
     """Task object: inputs and results of one segmentation (``str(task)`` prints segments)."""
 
@@ -170,6 +176,39 @@ class CTCSegmentation:
             if self.keep_lpz_on_device and lpz.is_cuda:
                 return lpz.to(torch.float32).contiguous()
             return lpz.cpu().numpy()
+
+    def get_lpz_batch(self, speeches, frames_fn=None):
+        """Many waveforms -> list of [T_i, V] log-posteriors from ONE padded encoder forward
+        (SURVEY.md §8f N1).  ``wav_lens`` carries the relative lengths, SpeechBrain's convention
+        for padded batches.  ``frames_fn(n_samples) -> T_i`` says how many leading frames belong
+        to an item (``wav2vec2_frames`` for the wav2vec2/HuBERT feature extractor); the default
+        is SpeechBrain's own ``round(relative_length * T_max)``.
+        Not the reference's numerics for models with self-attention: the reference encodes every
+        window alone (``wav_lens=[1.0]``, src/test/test_asr.py:35), a padded batch lets the
+        model's length mask decide what the padding contributes.  Convolution-only encoders give
+        identical frames.  Callers opt in (``anchor.run_batched(..., batch_lpz=True)``)."""
+        with torch.no_grad():
+            waves = [torch.as_tensor(s) for s in speeches]
+            lens = [int(w.shape[0]) for w in waves]
+            n_max = max(lens)
+            device = getattr(self.asr_model, "device", "cpu")
+            batch = torch.zeros(len(waves), n_max, dtype=waves[0].dtype)
+            for i, w in enumerate(waves):
+                batch[i, : lens[i]] = w
+            wav_lens = torch.tensor([n / n_max for n in lens], dtype=torch.float32)
+            enc = self._encode(batch.to(device), wav_lens.to(device))
+            lpz = self._ctc(enc).detach()
+            t_max = lpz.shape[1]
+            out = []
+            for i, n in enumerate(lens):
+                t_i = int(frames_fn(n)) if frames_fn is not None else int(round(n / n_max * t_max))
+                t_i = max(1, min(t_max, t_i))
+                item = lpz[i, :t_i]
+                if self.keep_lpz_on_device and item.is_cuda:
+                    out.append(item.to(torch.float32).contiguous())
+                else:
+                    out.append(item.cpu().numpy())
+            return out
 
     # -- text ----------------------------------------------------------------------------
     def _split_text(self, text):

@@ -280,9 +280,11 @@ def run_sequential(coroutine, aligner):
         return stop.value
 
 
-def run_batched(coroutines, aligner):
+def run_batched(coroutines, aligner, batch_lpz=False, frames_fn=None):
     """Advance many file coroutines in lockstep; all DP requests pending in a round go to the
-    engine in one launch (``aligner.get_segments_batch``).  Returns the result lists in order."""
+    engine in one launch (``aligner.get_segments_batch``).  With ``batch_lpz`` the emission
+    requests of a round also share one padded encoder forward (``aligner.get_lpz_batch``; see
+    its note on numerics).  Returns the result lists in order."""
     results = [None] * len(coroutines)
     pending = {}
     for i, co in enumerate(coroutines):
@@ -294,8 +296,12 @@ def run_batched(coroutines, aligner):
     while pending:
         answers = {}
         dp = [(i, r) for i, r in pending.items() if r[0] == "segments"]
-        for i, r in pending.items():
-            if r[0] == "lpz":
+        lz = [(i, r) for i, r in pending.items() if r[0] == "lpz"]
+        if batch_lpz and len(lz) > 1 and hasattr(aligner, "get_lpz_batch"):
+            for (i, _), lpz in zip(lz, aligner.get_lpz_batch([r[1] for _, r in lz], frames_fn=frames_fn)):
+                answers[i] = lpz
+        else:
+            for i, r in lz:
                 answers[i] = aligner.get_lpz(r[1])
         if dp and batch_fn is not None:
             tasks, owners = [], []

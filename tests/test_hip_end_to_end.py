@@ -105,3 +105,26 @@ def test_device_resident_emissions_match_host_path(pkg):
     for a, b in zip(res_d, res_h):
         assert np.array_equal(a["timings"], b["timings"]) and np.array_equal(a["char_probs"], b["char_probs"])
         assert a["segments"] == b["segments"] and a["state_list"] == b["state_list"]
+
+
+def test_batched_device_emissions_feed_the_dp(pkg):
+    """get_lpz_batch on a GPU model with keep_lpz_on_device: one padded forward, the per-window
+    matrices stay in HBM and go straight into one DP launch."""
+    asr_gpu = FakeASR(seed=12, device="cuda:0")
+    al = pkg.CTCSegmentation(asr_gpu, kaldi_style_text=False, time_stamps="fixed", scoring_length=30,
+                             keep_lpz_on_device=True)
+    host = pkg.CTCSegmentation(FakeASR(seed=12), kaldi_style_text=False, time_stamps="fixed", scoring_length=30)
+    audio = NoiseAudio(40.0, 77)
+    texts = [["HOLA QUE TAL", "MUY BIEN"], ["ADIOS AMIGOS"], ["UNO DOS TRES", "CUATRO", "CINCO SEIS"], ["SI"]]
+    waves = []
+    for i in range(len(texts)):
+        clip, sr = audio.load(16000 * 4 * i, 16000 * (5 + 2 * i) + 37 * i)
+        waves.append(asr_gpu.audio_normalizer(clip, sr))
+    lpzs = al.get_lpz_batch(waves, frames_fn=pkg.wav2vec2_frames)
+    assert all(z.is_cuda for z in lpzs)
+    assert [z.shape[0] for z in lpzs] == [pkg.wav2vec2_frames(w.shape[0]) for w in waves]
+    tasks_d = [al.prepare_segmentation_task(t, z, f"u{i}", w.shape[0]) for i, (t, z, w) in enumerate(zip(texts, lpzs, waves))]
+    tasks_h = [host.prepare_segmentation_task(t, z.cpu().numpy(), f"u{i}", w.shape[0])
+               for i, (t, z, w) in enumerate(zip(texts, lpzs, waves))]
+    for a, b in zip(al.get_segments_batch(tasks_d), host.get_segments_batch(tasks_h)):
+        assert np.array_equal(a["timings"], b["timings"]) and a["segments"] == b["segments"]

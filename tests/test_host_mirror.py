@@ -86,3 +86,27 @@ def test_aligner_protocol_until_the_dp(pkg):
     kw = dict(min_window_size=80000, max_window_size=100000, gratis_blank=False, set_blank=0)  # test_ctc_segmentation.py:20-25
     al3 = pkg.CTCSegmentation(asr, kaldi_style_text=False, **kw)
     assert al3.config.min_window_size == 80000 and al3.config.blank == 0
+
+
+def test_batched_emissions_one_padded_forward(pkg):
+    """get_lpz_batch: one padded encoder call; with a convolution-only encoder every item's
+    frames equal the batch-of-1 result the reference computes."""
+    import torch
+    asr = FakeASR(seed=2)
+    calls = []
+    enc = asr.encode_batch
+    asr.encode_batch = lambda wavs, lens: (calls.append((tuple(wavs.shape), lens.tolist())), enc(wavs, lens))[1]
+    al = pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed")
+    g = torch.Generator().manual_seed(5)
+    waves = [torch.randn(n, generator=g) for n in (48000, 16000 * 7 + 123, 400, 31999)]
+    singles = [al.get_lpz(w) for w in waves]
+    calls.clear()
+    batch = al.get_lpz_batch(waves, frames_fn=pkg.wav2vec2_frames)
+    assert len(calls) == 1 and calls[0][0] == (4, 16000 * 7 + 123)
+    np.testing.assert_allclose(calls[0][1], [n / (16000 * 7 + 123) for n in (48000, 16000 * 7 + 123, 400, 31999)], rtol=1e-6)
+    for s, b in zip(singles, batch):
+        assert s.shape == b.shape and b.dtype == np.float32
+        np.testing.assert_allclose(b, s, rtol=2e-6, atol=2e-6)  # the batched matmul blocks differently: a few ulp
+    # default frame rule (SpeechBrain's relative lengths) is within one frame of the exact count
+    for s, b in zip(singles, al.get_lpz_batch(waves)):
+        assert abs(b.shape[0] - s.shape[0]) <= 1
