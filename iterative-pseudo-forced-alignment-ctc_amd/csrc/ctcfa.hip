@@ -372,7 +372,15 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
                 s.wcol_off = pl->win_cols;
                 pl->win_table_floats += (int64_t)T[b] * C[b];
                 pl->win_cols += C[b];
-                pl->lds_win = std::max(pl->lds_win, (int)T[b] * 4);
+                // T floats at least (char_probs for the scoring); room for two columns of the first
+                // window, or of the whole trellis when that still fits, lets the fill double-buffer
+                {
+                    const int64_t W0 = std::min<int64_t>(T[b], params->min_window_size);
+                    int64_t want = std::max<int64_t>((int64_t)T[b] * 4, W0 * 8);
+                    if ((int64_t)T[b] * 8 <= (int64_t)eng->lds_limit) want = (int64_t)T[b] * 8;
+                    want = std::min<int64_t>(want, eng->lds_limit);
+                    pl->lds_win = std::max(pl->lds_win, (int)want);
+                }
                 pl->win_list.push_back(b);
             }
         }
@@ -516,6 +524,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.L = pl->prm.score_min_mean_over_L;
         wp.min_window = pl->prm.min_window_size;
         wp.max_window = pl->prm.max_window_size;
+        wp.lds_bytes = pl->lds_win;
         wp.dur = pl->prm.index_duration;
         hipLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
                            pl->lds_win, st, pl->d_segs, pl->d_win_list, a.d_lpz, a.d_labels,

@@ -799,6 +799,7 @@ struct WinParams {
     uint32_t flags;
     int L;
     int min_window, max_window;
+    int lds_bytes;  // dynamic LDS given to the kernel
     double dur;
 };
 
@@ -851,13 +852,20 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
             if (st) st[t] = -2;
         }
         __syncthreads();
-        if (wave == 0) {
-            // ------------------------------- fill ------------------------------------------
-            const float mean_offset = (float)((double)(T - W) / (double)C);
-            const int higher_offset = (int)mean_offset + 1;
-            int offset_sum = 0, last_arg = -1;
-            const int nchunk = (W + 63) / 64;
-            for (int c = 0; c < C; ++c) {
+        // Two column buffers when they fit: wave 0 then never stores to HBM (vmcnt retires in
+        // order on gfx9 -- its emission prefetch would wait for the previous chunk's table store in
+        // every chunk) and waves 1..3 copy the finished column to the table while the next one is
+        // being computed.  Otherwise one buffer, updated in place, and wave 0 stores itself.
+        const bool dbl = (int64_t)W * 8 <= (int64_t)p.lds_bytes;
+        // ------------------------------- fill ------------------------------------------
+        const float mean_offset = (float)((double)(T - W) / (double)C);
+        const int higher_offset = (int)mean_offset + 1;
+        int offset_sum = 0, last_arg = -1;
+        const int nchunk = (W + 63) / 64;
+        for (int c = 0; c < C; ++c) {
+            float* colw = col + ((dbl && (c & 1)) ? W : 0);         // this column
+            const float* colr = col + ((dbl && !(c & 1)) ? W : 0);  // previous column
+            if (wave == 0) {
                 int off = 0;
                 if (c > 0) {
                     int a = last_arg - W / 2;
@@ -869,14 +877,16 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                 }
                 if (lane == 0) __hip_atomic_store(offsets + c, offset_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int g = seg_lab[c];  // -1 for c == 0
-                float best_v = 0.0f;
-                int best_t = -1;
+                // first maximum of the column: every lane keeps the best of its own rows (ascending t,
+                // strict '>' keeps the first), the lanes are reduced once per column
+                float best_v = -__builtin_inff();
+                int best_t = 0x7fffffff;
                 float carry = 0.0f;  // x of the row before this chunk
                 // previous column's value for the switch candidate of row t: col[t - 1 + off]
                 auto load_prev = [&](int t0) -> float {
                     const int t = t0 + lane;
                     const int r = t - 1 + off;
-                    return (c > 0 && t < W && r >= 0 && r < W) ? col[r] : pm;
+                    return (c > 0 && t < W && r >= 0 && r < W) ? colr[r] : pm;
                 };
                 float pin = load_prev(0);
                 float* tcol = table + (int64_t)c * W;
@@ -885,76 +895,98 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                 auto load_em = [&](int t0, float& e_out, float& lb_out) {
                     const int t = t0 + lane;
                     const int f = (t < W) ? t + offset_sum : T - 1;
+                    // raw loads only (any arithmetic on the results here would make the wave wait
+                    // for them a chunk early); column 0 has no label: read the blank entry, unused
                     lb_out = seg_lpz[(int64_t)f * V + p.blank];
-                    e_out = (c > 0) ? seg_lpz[(int64_t)f * V + g] : 0.0f;
+                    e_out = seg_lpz[(int64_t)f * V + (c > 0 ? g : p.blank)];
                 };
-                float e_cur, lb_cur;
-                load_em(0, e_cur, lb_cur);
-                for (int ch = 0; ch < nchunk; ++ch) {
-                    const int t0 = ch * 64;
-                    const int t = t0 + lane;
-                    const bool valid = t < W;
-                    const float pin_next = load_prev(t0 + 64);  // read before this chunk overwrites col[]
-                    float e_next, lb_next;
-                    load_em(t0 + 64, e_next, lb_next);
-                    const float lb = lb_cur;
-                    float b, m;
-                    if (c > 0) {
-                        const float e = e_cur;
-                        const int r = t - 1 + off;
-                        const float pcand = (r >= W || r < 0) ? pm : pin + e;
-                        b = pcand > pm ? pcand : pm;           // switch_prob = max(prob_max, p)
-                        const float mlpz = e > pm ? e : pm;    // max_lpz_prob
-                        m = mlpz > lb ? mlpz : lb;             // max(lpz[blank], max_lpz_prob)
-                    } else {
-                        b = (t == 0) ? 0.0f : pm;              // table[0,0] = 0; no switch into column 0
-                        m = preamble ? 0.0f : (pm > lb ? pm : lb);
-                    }
-                    // chain: lane i <- max(b_i, x_{i-1} + m_i).  Row 0 has no stay candidate: m = -inf
-                    // there makes the sum lose against b >= -1e9.  Two VALU per step: the add reads
-                    // lane i-1 through DPP (lane 0 has no source lane and keeps carry + m_0).
-                    if (t == 0) m = -__builtin_inff();
-                    float tmp = carry + m;
-                    float x = __builtin_fmaxf(tmp, b);
-#pragma unroll 9
-                    for (int it = 0; it < 63; ++it) {
-                        // s_nop 1: a DPP operand written by the previous VALU needs two wait states,
-                        // and the hazard recogniser does not look inside inline asm
-                        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                                     : "+v"(tmp) : "v"(x), "v"(m));
-                        x = __builtin_fmaxf(tmp, b);
-                    }
-                    if (valid) {
-                        col[t] = x;
-                        tcol[t] = x;
-                    }
-                    // first maximum of the column (rows t >= 1 for column 0), strict '<' to replace
-                    {
-                        const bool counted = valid && !(c == 0 && t == 0);
-                        float cm = counted ? x : -__builtin_inff();
+                // Chunks go in groups of G: the emissions of the NEXT group are requested at the top of
+                // a group (the compiler drains vmcnt at the loop's back edge, so a group has to be
+                // long enough -- G chains -- to cover the gather latency).
+                constexpr int G = 4;
+                float e_cur[G], lb_cur[G], e_nxt[G], lb_nxt[G];
 #pragma unroll
-                        for (int o = 32; o >= 1; o >>= 1) {
-                            const float ov = __shfl_xor(cm, o);
-                            cm = ov > cm ? ov : cm;
+                for (int q = 0; q < G; ++q) load_em(q * 64, e_cur[q], lb_cur[q]);
+                for (int ch0 = 0; ch0 < nchunk; ch0 += G) {
+#pragma unroll
+                    for (int q = 0; q < G; ++q) load_em((ch0 + G + q) * 64, e_nxt[q], lb_nxt[q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        const int ch = ch0 + q;
+                        if (ch >= nchunk) break;  // uniform
+                        const int t0 = ch * 64;
+                        const int t = t0 + lane;
+                        const bool valid = t < W;
+                        const float pin_next = load_prev(t0 + 64);  // read before this chunk overwrites col[]
+                        const float lb = lb_cur[q];
+                        float b, m;
+                        if (c > 0) {
+                            const float e = e_cur[q];
+                            const int r = t - 1 + off;
+                            const float pcand = (r >= W || r < 0) ? pm : pin + e;
+                            b = pcand > pm ? pcand : pm;           // switch_prob = max(prob_max, p)
+                            const float mlpz = e > pm ? e : pm;    // max_lpz_prob
+                            m = mlpz > lb ? mlpz : lb;             // max(lpz[blank], max_lpz_prob)
+                        } else {
+                            b = (t == 0) ? 0.0f : pm;              // table[0,0] = 0; no switch into column 0
+                            m = preamble ? 0.0f : (pm > lb ? pm : lb);
                         }
-                        const unsigned long long eq = __builtin_amdgcn_ballot_w64(counted && x == cm);
-                        if (eq != 0ull) {
-                            const int fl = __builtin_ctzll(eq);
-                            if (best_t == -1 || best_v < cm) {
-                                best_v = cm;
-                                best_t = t0 + fl;
+                        // chain: lane i <- max(b_i, x_{i-1} + m_i).  Row 0 has no stay candidate: m = -inf
+                        // there makes the sum lose against b >= -1e9.  Two VALU per step: the add reads
+                        // lane i-1 through DPP (lane 0 has no source lane and keeps carry + m_0).
+                        if (t == 0) m = -__builtin_inff();
+                        float tmp = carry + m;
+                        float x = __builtin_fmaxf(tmp, b);
+#pragma unroll 9
+                        for (int it = 0; it < 63; ++it) {
+                            // s_nop 1: a DPP operand written by the previous VALU needs two wait states,
+                            // and the hazard recogniser does not look inside inline asm
+                            asm volatile("s_nop 1\n\t"
+                                         "v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                                         "v_max_f32 %1, %0, %3"
+                                         : "+v"(tmp), "+v"(x) : "v"(m), "v"(b));
+                        }
+                        if (valid) {
+                            colw[t] = x;
+                            if (!dbl) tcol[t] = x;
+                        }
+                        {   // rows t >= 1 only for column 0 (the package's loop starts there)
+                            const bool counted = valid && !(c == 0 && t == 0);
+                            if (counted && (best_t == 0x7fffffff || x > best_v)) {
+                                best_v = x;
+                                best_t = t;
                             }
                         }
+                        const int lastl = (W - 1 - t0) < 63 ? (W - 1 - t0) : 63;
+                        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lastl));
+                        pin = pin_next;
                     }
-                    const int lastl = (W - 1 - t0) < 63 ? (W - 1 - t0) : 63;
-                    carry = __shfl(x, lastl);
-                    pin = pin_next;
-                    e_cur = e_next;
-                    lb_cur = lb_next;
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        e_cur[q] = e_nxt[q];
+                        lb_cur[q] = lb_nxt[q];
+                    }
                 }
-                last_arg = best_t;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const float ov = __shfl_xor(best_v, o);
+                    const int ot = __shfl_xor(best_t, o);
+                    if (ot != 0x7fffffff && (best_t == 0x7fffffff || ov > best_v || (ov == best_v && ot < best_t))) {
+                        best_v = ov;
+                        best_t = ot;
+                    }
+                }
+                last_arg = (best_t == 0x7fffffff) ? -1 : best_t;
+            }  // wave 0
+            __syncthreads();
+            if (dbl && wave != 0) {  // column c -> table, while wave 0 goes on with column c+1
+                float* tcol = table + (int64_t)c * W;
+                for (int t = tid - 64; t < W; t += kWinThreads - 64) tcol[t] = colw[t];
             }
-            __threadfence();
+        }
+        __threadfence();
+        __syncthreads();
+        if (wave == 0) {
             // ------------------------------- walk (lane 0) ---------------------------------
             int err = 0;
             int te = (p.flags & 4u) ? W - 1 : last_arg;
