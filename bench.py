@@ -204,6 +204,36 @@ def main():
                "sample": f"{reps} pass(es) over {ns} of the {B} benchmark segments ({T} frames x {C} columns), "
                          f"oracle/ctc_segmentation_oracle.c, single thread, {sec:.1f} s",
                "host_cores": os.cpu_count()}
+        # SURVEY §8(d)'s baseline definition -- what n_process=1 executes per DP call in the
+        # reference: a compiled fill (the C oracle's fill stands in for the Cython one) followed by
+        # the package's interpreted backtrack and scoring loops (the NumPy twin, laid out like the
+        # package).  A handful of segments is enough: ~0.1 s each.
+        try:
+            from oracle import ctc_segmentation_twin as tw
+            import time as _time
+
+            def _compiled_fill(table, lpz_b, gt_b, offsets, blank, flags):
+                tb, offs, t_end = oracle_c.fill_table(lpz_b, gt_b, table.shape[0], blank, flags)
+                table[...] = tb
+                offsets[...] = offs
+                return t_end, table.shape[1] - 1
+
+            tw_fill, tw.cython_fill_table = tw.cython_fill_table, _compiled_fill
+            conf = tw.CtcSegmentationParameters(index_duration=INDEX_DURATION)
+            k, t0 = 0, _time.perf_counter()
+            while k < min(8, B) and _time.perf_counter() - t0 < 3.0:
+                tim, cps, _ = tw.ctc_segmentation(conf, lpz[k], np.asarray(gt[k]).reshape(-1, 1))
+                tw.determine_utterance_segments(conf, ub[k], cps, tim, [""] * (len(ub[k]) - 1))
+                k += 1
+            sec2 = _time.perf_counter() - t0
+            tw.cython_fill_table = tw_fill
+            cpu["reference_structured"] = {
+                "frames_per_s": k * T / sec2, "value": k * T / sec2 * INDEX_DURATION / 3600.0,
+                "unit": "audio-hours/s", "cores": 1,
+                "sample": f"{k} segments: compiled fill (C oracle) + interpreted backtrack and scoring "
+                          f"(oracle/ctc_segmentation_twin.py), {sec2:.1f} s"}
+        except Exception as exc:  # the headline baseline above does not depend on this
+            cpu["reference_structured"] = {"error": repr(exc)}
 
     # HBM bytes per launch of the dominant kernel: PMC counters are collected in separate
     # rocprofv3 --pmc passes (tools/collect_traffic.sh) and committed under profiles/; the
