@@ -42,6 +42,7 @@ struct ctcfa_plan {
     hipEvent_t ev_fill_done[2] = {nullptr, nullptr};
     hipEvent_t ev_bt_done[2] = {nullptr, nullptr};
     bool bt_pending[2] = {false, false};
+    hipEvent_t bt_done_ev[2] = {nullptr, nullptr};  // the event that marks workspace q free again
     int64_t pipe_runs = 0;
     // event ring: 4 events per recorded run (fill start/end, backtrack start/end)
     std::vector<hipEvent_t> ev;
@@ -463,6 +464,12 @@ int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
 int ctcfa_plan_set_timing(ctcfa_plan* pl, int slots) {
     if (!pl || slots < 0 || slots > 4096) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
+    if (slots > 0 && slots < 4) slots = 4;  // the pipelined entry waits on the event of run k-2
+    if (pl->side && (pl->bt_pending[0] || pl->bt_pending[1])) {
+        // a pending hand-over may be one of the timing events about to be destroyed
+        HIP_TRY(eng, hipStreamSynchronize(pl->side));
+        pl->bt_pending[0] = pl->bt_pending[1] = false;
+    }
     for (auto& e : pl->ev)
         if (e) (void)hipEventDestroy(e);
     pl->ev.assign((size_t)slots * 4, nullptr);
@@ -594,20 +601,22 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     }
     const int q = (int)(pl->pipe_runs & 1);
     // workspace q was last read by the backtrack of run k-2
-    if (pl->bt_pending[q]) HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[q], 0));
-    hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
+    if (pl->bt_pending[q]) HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
+    // With timing on, the "end" timing events double as the hand-over events: every event record
+    // is a packet the queue has to retire between two kernels.  (The ring has >= 4 slots, so the
+    // event of run k is still untouched when run k+2 waits on it.)
+    hipEvent_t* ev = pl->ev_slots >= 4 ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
     if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
     if ((rc = launch_fill(pl, a, q, st)) != CTCFA_OK) return rc;
-    if (ev) HIP_TRY(eng, hipEventRecord(ev[1], st));
-    HIP_TRY(eng, hipEventRecord(pl->ev_fill_done[q], st));
-    HIP_TRY(eng, hipStreamWaitEvent(pl->side, pl->ev_fill_done[q], 0));
+    hipEvent_t fill_done = ev ? ev[1] : pl->ev_fill_done[q];
+    HIP_TRY(eng, hipEventRecord(fill_done, st));
+    HIP_TRY(eng, hipStreamWaitEvent(pl->side, fill_done, 0));
     if (ev) HIP_TRY(eng, hipEventRecord(ev[2], pl->side));
     if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side)) != CTCFA_OK) return rc;
-    if (ev) {
-        HIP_TRY(eng, hipEventRecord(ev[3], pl->side));
-        pl->ev_runs++;
-    }
-    HIP_TRY(eng, hipEventRecord(pl->ev_bt_done[q], pl->side));
+    hipEvent_t bt_done = ev ? ev[3] : pl->ev_bt_done[q];
+    HIP_TRY(eng, hipEventRecord(bt_done, pl->side));
+    if (ev) pl->ev_runs++;
+    pl->bt_done_ev[q] = bt_done;
     pl->bt_pending[q] = true;
     pl->pipe_runs++;
     return CTCFA_OK;
@@ -619,7 +628,7 @@ int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     for (int q = 0; q < 2; ++q)
         if (pl->bt_pending[q]) {
-            HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[q], 0));
+            HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
             pl->bt_pending[q] = false;
         }
     return CTCFA_OK;
