@@ -150,10 +150,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const int nsteps = nblk + W - 1;
 
     for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = kProbMax;
-    if (tid == 0) *posflag = 0;
 
-    if (my.role == kRoleIdle) return;  // a finished wave no longer counts at s_barrier
+    if (my.role == kRoleIdle) {
+        lds_barrier();  // its share of the ring initialisation is visible; from here on a
+        return;         // finished wave no longer counts at s_barrier
+    }
     if (my.role == kRoleProducer) {
+        if (lane == 0) *posflag = 0;  // same wave as every later write of the flag: ordered
         // ============================ producer wave ===========================================
         // Block jb = rows t in [32*jb + 1, 32*jb + 32].  One pass of the wave covers 64/VP rows
         // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
