@@ -365,7 +365,8 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         if (C[b] > T[b]) s.prestatus = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
         else if (T[b] > params->min_window_size) {
             // windowed regime: own kernel, needs T floats of LDS and a T x C fp32 table in HBM
-            if ((int64_t)T[b] * 4 > (int64_t)eng->lds_limit) {
+            const int64_t lds_dyn_max = (int64_t)eng->lds_limit - 64;  // the kernel also has a few static words
+            if ((int64_t)T[b] * 4 > lds_dyn_max) {
                 s.prestatus = CTCFA_ST_WINDOWED_UNSUPPORTED;
             } else {
                 s.prestatus = ctcfa::kPreWindowed;
@@ -378,8 +379,8 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
                 {
                     const int64_t W0 = std::min<int64_t>(T[b], params->min_window_size);
                     int64_t want = std::max<int64_t>((int64_t)T[b] * 4, W0 * 8);
-                    if ((int64_t)T[b] * 8 <= (int64_t)eng->lds_limit) want = (int64_t)T[b] * 8;
-                    want = std::min<int64_t>(want, eng->lds_limit);
+                    if ((int64_t)T[b] * 8 <= lds_dyn_max) want = (int64_t)T[b] * 8;
+                    want = std::min<int64_t>(want, lds_dyn_max);
                     pl->lds_win = std::max(pl->lds_win, (int)want);
                 }
                 pl->win_list.push_back(b);

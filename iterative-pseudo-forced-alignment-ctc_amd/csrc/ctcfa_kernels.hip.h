@@ -469,6 +469,10 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if (lane < kRows && t >= 1 && t < T)
                     seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
             }
+            // A tile that stops here (dead zone) will not open another group: hand its last row over
+            // now -- the next tile's first column is alive one row longer than this tile's last one.
+            if (j == jlast && jlast < nblk - 1 && lane == 63 && w < wstar)
+                bnd[(w + 1) * kBndPitch + ((j + 1) * kRows) % kBnd] = pub4.x;
         }
         lds_barrier();
     }

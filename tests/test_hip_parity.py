@@ -486,3 +486,59 @@ def test_windowed_regime_failed_backtracks_and_window_doubling(pkg, oracle, mw):
         _check(pkg, oracle, segs, res, cfg_kw=kw)
         n_fail[mx] = sum(int(r["status"]) == 2 for r in res)
     assert n_fail[mw + 1] >= 3 and n_fail[100000] == 0 and n_fail[2 * mw + 1] < n_fail[mw + 1]
+
+
+def _fuzz_segment(rng, V, blank, Tmax):
+    U = int(rng.integers(0, 9))
+    n = int(rng.integers(1, 30))
+    gt, ub = __import__("importlib").import_module("iterative-pseudo-forced-alignment-ctc_amd").synthetic.make_labels(rng, U, n, V, blank=blank)
+    C = len(gt)
+    lo = max(2, C - 3)                      # a few segments with T < C (status 1)
+    T = int(rng.integers(lo, max(lo + 1, min(Tmax, 6 * C + 40))))
+    kind = int(rng.integers(0, 5))
+    if kind == 0:       # flat: every path ties
+        lpz = np.full((T, V), np.float32(np.log(1.0 / V)))
+    elif kind == 1:     # coarse grid
+        lpz = (np.round(rng.uniform(-12, 0, size=(T, V)) * 2) / 2).astype(np.float32)
+    elif kind == 2:     # peaky noise
+        lpz = np.log(rng.dirichlet(np.ones(V) * 0.1, size=T) + 1e-30).astype(np.float32)
+    elif kind == 3:     # raw logits (positive values: the -1e9 shortcut must switch off)
+        lpz = (rng.standard_normal((T, V)) * 4).astype(np.float32)
+    else:               # smooth log-softmax noise
+        x = rng.standard_normal((T, V)) * 2
+        lpz = (x - np.log(np.exp(x).sum(1, keepdims=True))).astype(np.float32)
+    return lpz, gt, ub
+
+
+@pytest.mark.parametrize("V,blank", [(5, 0), (17, 3), (32, 0), (33, 32), (64, 1), (100, 0), (128, 127)])
+@pytest.mark.parametrize("flags", [dict(), dict(preamble_transition_cost_zero=False), dict(backtrack_from_max_t=True)])
+def test_fuzz_shapes_vocabularies_and_flags(pkg, oracle, V, blank, flags):
+    """Random ragged batches over vocabulary sizes (all three LDS row pitches), blank positions,
+    flag combinations and scoring lengths; emissions from exact ties to raw logits."""
+    rng = np.random.default_rng(7000 + 131 * V + blank + 17 * len(flags))
+    segs = [_fuzz_segment(rng, V, blank, 700) for _ in range(40)]
+    L = int(rng.integers(1, 129))
+    kw = dict(blank=blank, score_min_mean_over_L=L, **flags)
+    res = _run(pkg, segs, **kw)
+    _check(pkg, oracle, segs, res, cfg_kw=kw)
+    assert any(r["status"] == 0 for r in res)
+
+
+@pytest.mark.parametrize("batch", [3, 300])
+def test_path_along_the_dead_zone_boundary(pkg, oracle, batch):
+    """backtrack_from_max_t with flat emissions: the path is the last diagonal that can still
+    reach the end cell, i.e. it runs along the edge of the region the fill kernel skips, and with
+    T - C == 1 (mod 32) every tile stops exactly at a block end (regression: the tile's last row
+    was never handed to the next tile).  batch 300 takes the mixed 8-wave shape."""
+    segs = []
+    for s in range(3):
+        gt, ub = pkg.synthetic.make_labels(np.random.default_rng(5000 + s), 22, 28, 32)
+        C = len(gt)
+        T = C + 1 + 32 * (3 + 4 * s)
+        segs.append((np.full((T, 32), np.float32(np.log(1.0 / 32.0))), gt, ub))
+    segs = [segs[i % 3] for i in range(batch)]
+    for kw in (dict(backtrack_from_max_t=True), dict()):
+        res = _run(pkg, segs, **kw)
+        _check(pkg, oracle, segs[:3], res[:3], cfg_kw=kw)
+        for i in range(3, batch):
+            assert np.array_equal(res[i]["frame_of_label"], res[i % 3]["frame_of_label"])

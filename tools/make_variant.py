@@ -59,6 +59,12 @@ def patch_G(k, h):
     return k, h
 
 
+def patch_F(k, h):
+    """regression aid: without the hand-over of a stopping tile's last row (the bug the fuzz test found)"""
+    k = sub(k, "bnd[(w + 1) * kBndPitch + ((j + 1) * kRows) % kBnd] = pub4.x;", ";")
+    return k, h
+
+
 def patch_stamp(k, h):
     stamp_def = """
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(seg_lastcol);
@@ -99,7 +105,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
