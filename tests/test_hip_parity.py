@@ -542,3 +542,94 @@ def test_path_along_the_dead_zone_boundary(pkg, oracle, batch):
         _check(pkg, oracle, segs[:3], res[:3], cfg_kw=kw)
         for i in range(3, batch):
             assert np.array_equal(res[i]["frame_of_label"], res[i % 3]["frame_of_label"])
+
+
+def _run_plan(pkg, engine, segs, K=0, **cfg):
+    """Plan API with device buffers and an optional forced tile width; same result dicts as _run."""
+    import torch
+
+    config = pkg.CtcSegmentationParameters(index_duration=DUR, **cfg)
+    V = segs[0][0].shape[1]
+    T = [s[0].shape[0] for s in segs]
+    C = [len(s[1]) for s in segs]
+    U = [len(s[2]) - 1 for s in segs]
+    plan = engine.plan(config.to_native(), V, T, C, U, force_cols_per_lane=K)
+    dev = torch.device("cuda:0")
+    d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in segs])).to(dev)
+    d_lab = torch.from_numpy(np.concatenate([s[1] for s in segs]).astype(np.int32)).to(dev)
+    d_ub = torch.from_numpy(np.concatenate([s[2] for s in segs]).astype(np.int32)).to(dev)
+    nT, nC, nU = sum(T), sum(C), max(1, sum(U))
+    d_fol = torch.empty(nC, dtype=torch.int32, device=dev)
+    d_cp = torch.empty(nT, dtype=torch.float32, device=dev)
+    d_st = torch.empty(nT, dtype=torch.int32, device=dev)
+    d_seg = torch.empty(3, nU, dtype=torch.float64, device=dev)
+    d_te = torch.empty(len(segs), dtype=torch.int32, device=dev)
+    d_status = torch.empty(len(segs), dtype=torch.int32, device=dev)
+    plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), d_fol.data_ptr(), d_cp.data_ptr(),
+                    d_st.data_ptr(), d_seg[0].data_ptr(), d_seg[1].data_ptr(), d_seg[2].data_ptr(),
+                    d_te.data_ptr(), d_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    info = plan.info
+    plan.close()
+    fol, cp, st = d_fol.cpu().numpy(), d_cp.cpu().numpy(), d_st.cpu().numpy()
+    seg, te, status = d_seg.cpu().numpy(), d_te.cpu().numpy(), d_status.cpu().numpy()
+    to, co, uo = (np.concatenate([[0], np.cumsum(x)]) for x in (T, C, U))
+    return [dict(status=int(status[b]), t_end=int(te[b]), frame_of_label=fol[co[b]:co[b + 1]],
+                 char_prob=cp[to[b]:to[b + 1]], state=st[to[b]:to[b + 1]], seg_start=seg[0][uo[b]:uo[b + 1]],
+                 seg_end=seg[1][uo[b]:uo[b + 1]], seg_score=seg[2][uo[b]:uo[b + 1]]) for b in range(len(segs))], info
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_medium_shapes_tiles_and_zones(pkg, oracle, engine, seed):
+    """Ragged batches up to T = 2500 / C = 900 over forced tile widths (and the automatic choice,
+    which takes the mixed 8-wave shape for the large batches), with paths that end anywhere from
+    the first feasible frame to T-1: the regions the fill kernel skips change with every
+    segment.  Flags and scoring length vary per run."""
+    rng = np.random.default_rng(8000 + seed)
+    syn = pkg.synthetic
+    K = [0, 1, 2, 3, 5, 0, 2, 4][seed]
+    batch = 270 if seed in (0, 5) else 20
+    segs = []
+    for s in range(batch):
+        U = int(rng.integers(1, 30))
+        n = int(rng.integers(2, 30))
+        gt, ub = syn.make_labels(rng, U, n, 32)
+        C = len(gt)
+        T = int(C + rng.integers(0, 4)) if rng.random() < 0.2 else int(rng.integers(C, max(C + 1, 2500)))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            lpz = np.full((T, 32), np.float32(np.log(1.0 / 32)))
+        elif kind == 1:   # sharp: the best path uses every frame
+            lpz = syn.make_emissions(rng, T, 32, gt, noise=0.5, peak=15.0)
+        elif kind == 2:
+            lpz = syn.make_emissions(rng, T, 32, gt)
+        else:
+            lpz = (np.round(rng.uniform(-9, 0, size=(T, 32)) * 2) / 2).astype(np.float32)
+        segs.append((lpz, gt, ub))
+    kw = dict(score_min_mean_over_L=int(rng.integers(1, 129)))
+    if seed % 3 == 1:
+        kw["backtrack_from_max_t"] = True
+    if seed % 4 == 2:
+        kw["preamble_transition_cost_zero"] = False
+    res, info = _run_plan(pkg, engine, segs, K, **kw)
+    if K:
+        assert info["cols_per_lane"] == K
+    _check(pkg, oracle, segs, res, cfg_kw=kw)
+
+
+@pytest.mark.parametrize("V,blank", [(5, 0), (32, 7), (64, 63), (128, 0)])
+@pytest.mark.parametrize("flags", [dict(), dict(preamble_transition_cost_zero=False), dict(backtrack_from_max_t=True)])
+def test_fuzz_windowed_regime(pkg, oracle, V, blank, flags):
+    """The windowed kernel over vocabularies, blank positions and flags; window sizes from 8 to
+    64 frames with every segment longer than the window, emissions from ties to raw logits."""
+    rng = np.random.default_rng(9000 + 7 * V + blank + 3 * len(flags))
+    mw = int(rng.choice([8, 16, 33, 64]))
+    segs = []
+    while len(segs) < 30:
+        s = _fuzz_segment(rng, V, blank, 500)
+        if s[0].shape[0] > mw:
+            segs.append(s)
+    for mx in (2 * mw + 1, 100000):
+        kw = dict(blank=blank, min_window_size=mw, max_window_size=mx,
+                  score_min_mean_over_L=int(rng.integers(1, 129)), **flags)
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
