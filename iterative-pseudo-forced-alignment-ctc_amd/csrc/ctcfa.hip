@@ -113,6 +113,9 @@ FillFn select_fill(int KH, int KL, int VP) {
     if (KL == KH) {
         switch (VP) {
             case 32: return fill_for_k<32>(KH);
+            case 40: return fill_for_k<40>(KH);
+            case 48: return fill_for_k<48>(KH);
+            case 56: return fill_for_k<56>(KH);
             case 64: return fill_for_k<64>(KH);
             case 128: return fill_for_k<128>(KH);
             default: return nullptr;
@@ -120,6 +123,9 @@ FillFn select_fill(int KH, int KL, int VP) {
     }
     switch (VP) {
         case 32: return fill_mixed<32>(KH);
+        case 40: return fill_mixed<40>(KH);
+        case 48: return fill_mixed<48>(KH);
+        case 56: return fill_mixed<56>(KH);
         case 64: return fill_mixed<64>(KH);
         case 128: return fill_mixed<128>(KH);
         default: return nullptr;
@@ -293,7 +299,10 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     pl->prm = *params;
     pl->B = batch;
     pl->V = vocab;
-    pl->VP = vocab <= 32 ? 32 : (vocab <= 64 ? 64 : 128);
+    // LDS row pitch: the vocabulary rounded up to a compiled size.  Character vocabularies of
+    // wav2vec2 models sit between 32 and 64 (the reference's Spanish model: 38 tokens), where
+    // a pitch of 64 would cost a second workgroup per CU.
+    pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64 : 128;
     pl->have_utt = (U != nullptr);
 
     int Cmax = 2, Tmax = 1;

@@ -162,14 +162,20 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
         // waves (registers double-buffered), so HBM latency never sits inside a step.
         constexpr int PASSES = kRows * VP / 64;
-        constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
+        // VP <= 64: the whole block travels in registers (two sets, swapped by 2x unrolling)
+        constexpr int CH = (VP <= 64) ? PASSES : 16;  // loads in flight per chunk
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
         bool notneg = false;  // any staged emission that is not <= 0 (NaN counts)
         auto publish_flag = [&]() {
             if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
         };
-        auto load_chunk = [&](int jb, int p0, float (&e)[CH]) {
+        auto load_chunk = [&](int jb, int p0, float (&e)[CH], float& lbv) {
             const int t0 = jb * kRows + 1;
+            if constexpr (VP <= 64) {  // lane r < 32 fetches the blank entry of row r of the block
+                int tb = t0 + (lane & 31);
+                tb = tb < T ? tb : T - 1;
+                lbv = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tb * V + blank) * 4u);
+            }
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 const int idx = (p0 + q) * 64 + lane;  // element of the block
@@ -180,7 +186,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 e[q] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V + svc) * 4u);
             }
         };
-        auto write_chunk = [&](int jb, int p0, const float (&e)[CH]) {
+        auto write_chunk = [&](int jb, int p0, const float (&e)[CH], float lbv) {
             unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
             const int t0 = jb * kRows + 1;
 #pragma unroll
@@ -190,12 +196,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const int r = idx / VP;
                 const int t = t0 + r;
                 float lb;
-                if constexpr (VP == 32) {  // two rows per pass: the row's blank entry via readlane
-                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
-                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), 32 + blank));
-                    lb = (lane < 32) ? lo : hi;
-                } else if constexpr (VP == 64) {
-                    lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
+                if constexpr (VP <= 64) {  // the row's blank entry sits in lane r of lbv
+                    lb = __shfl(lbv, r);
                 } else {
                     const int tc = t < T ? t : T - 1;
                     lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
@@ -209,7 +211,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
             }
         };
-        if (V == VP && VP <= 64) {
+        if ((VP == 32 || VP == 64) && V == VP) {  // (constant-folded away for the other pitches)
             // ---- vectorised staging (the common case V == 32): a lane loads 4 consecutive
             // entries of a row with one dwordx4, LPR lanes share a row, RPP rows per pass.
             constexpr int LPR = VP / 4;
@@ -269,22 +271,72 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }
                 lds_barrier();
             }
+        } else if constexpr (VP > 32 && VP <= 64) {
+            // ---- one row per pass (character vocabularies between 33 and 64 entries that are not
+            // a compiled pitch themselves, e.g. the reference's 38-token model): lane = vocabulary
+            // entry, the row's address is wave-uniform (scalar arithmetic), the blank entry comes
+            // from a v_readlane, LDS offsets are immediates.  Lane VP writes the start-column pseudo
+            // entry, the remaining lanes a sink.  ~6 instructions per row.
+            constexpr int kPseudoLane = VP < 64 ? VP : 63;  // V < VP here, so this lane carries no entry
+            const int svl = lane < V ? lane : V - 1;             // lanes past the vocabulary re-read its last entry
+            // LDS entry a lane writes: its own, the pseudo entry VP, or (lanes past VP) the pad entry VP+1
+            const uint32_t ent = static_cast<uint32_t>((lane == kPseudoLane ? VP : (lane <= VP ? lane : VP + 1)) * 8);
+            auto rload = [&](int jb, float (&e)[kRows]) {
+                const int t0 = jb * kRows + 1;
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    int t = t0 + r;
+                    t = t < T ? t : T - 1;
+                    e[r] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V) * 4u +
+                                                           static_cast<uint32_t>(svl) * 4u);
+                }
+            };
+            auto rwrite = [&](int jb, const float (&e)[kRows]) {
+                unsigned char* dst = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) + ent;
+                const int t0 = jb * kRows + 1;
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), blank));
+                    const bool valid = (t0 + r) < T;  // uniform
+                    notneg |= !(e[r] <= 0.0f);
+                    float2 v = make_float2(e[r], max3f(lb, e[r], kProbMax));
+                    if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                    if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
+                    *reinterpret_cast<float2*>(dst + r * (PITCH * 8)) = v;
+                }
+            };
+            float ea[kRows], eb[kRows];
+            rload(0, ea);
+            rwrite(0, ea);
+            publish_flag();
+            if (1 < nblk) rload(1, ea);
+            lds_barrier();
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 2 < nblk) rload(s + 2, eb);
+                if (s + 1 < nblk) { rwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
+                lds_barrier();
+                if (s + 1 >= nsteps) break;
+                if (s + 3 < nblk) rload(s + 3, ea);
+                if (s + 2 < nblk) { rwrite(s + 2, eb); publish_flag(); }
+                lds_barrier();
+            }
         } else if constexpr (PASSES == CH) {
 
             // whole block in one chunk (VP == 32): two register sets, swapped by 2x unrolling
             float ea[CH], eb[CH];
-            load_chunk(0, 0, ea);
-            write_chunk(0, 0, ea);
+            float la = 0.0f, lbb = 0.0f;
+            load_chunk(0, 0, ea, la);
+            write_chunk(0, 0, ea, la);
             publish_flag();
-            if (1 < nblk) load_chunk(1, 0, ea);
+            if (1 < nblk) load_chunk(1, 0, ea, la);
             lds_barrier();
             for (int s = 0; s < nsteps; s += 2) {
-                if (s + 2 < nblk) load_chunk(s + 2, 0, eb);
-                if (s + 1 < nblk) { write_chunk(s + 1, 0, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
+                if (s + 2 < nblk) load_chunk(s + 2, 0, eb, lbb);
+                if (s + 1 < nblk) { write_chunk(s + 1, 0, ea, la); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
                 lds_barrier();
                 if (s + 1 >= nsteps) break;
-                if (s + 3 < nblk) load_chunk(s + 3, 0, ea);
-                if (s + 2 < nblk) { write_chunk(s + 2, 0, eb); publish_flag(); }
+                if (s + 3 < nblk) load_chunk(s + 3, 0, ea, la);
+                if (s + 2 < nblk) { write_chunk(s + 2, 0, eb, lbb); publish_flag(); }
                 lds_barrier();
             }
         } else {
@@ -293,8 +345,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             auto stage_block = [&](int jb) {
 #pragma unroll 1
                 for (int p0 = 0; p0 < PASSES; p0 += CH) {
-                    load_chunk(jb, p0, e);
-                    write_chunk(jb, p0, e);
+                    float unused = 0.0f;
+                    load_chunk(jb, p0, e, unused);
+                    write_chunk(jb, p0, e, unused);
                 }
                 publish_flag();
             };

@@ -15,6 +15,8 @@ tools/collect_traffic.sh > $OUT/traffic.log 2>&1 && cp gpurun_out/pmc_traffic.js
 && cp $(ls gpurun_out/kstats_s/*/*_kernel_stats.csv | head -1) $OUT/${R}_kernel_stats_serial.csv \
 && timeout -k 10 600 python tools/sweep_shapes.py 2> $OUT/shapes.err | grep "^|" > $OUT/${R}_shapes.md \
 && timeout -k 10 300 python tools/windowed_timing.py 2>/dev/null | grep "T=" > $OUT/${R}_windowed.txt \
+&& timeout -k 10 300 python tools/vocab_sweep.py 2>/dev/null | grep "V=" > $OUT/${R}_vocab.txt \
+&& timeout -k 10 300 python tools/call_latency.py 2>/dev/null | grep "T=" > $OUT/${R}_call_latency.txt \
 && tools/pmc_lds.sh "2" > $OUT/${R}_pmc_lds.txt 2>&1 \
 && (timeout -k 10 120 ./tools/hwid_probe 6 58000; timeout -k 10 120 ./tools/hwid_probe 8 66000) > $OUT/${R}_wave_placement.txt 2>&1 \
 && (timeout -k 10 200 ./tools/valu_rate; timeout -k 10 120 ./tools/pk_rate; timeout -k 10 120 ./tools/lds_rate) > $OUT/${R}_issue_rates.txt 2>&1 \

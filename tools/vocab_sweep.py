@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Tuning aid: config-3-shaped batch (512 x 3000 frames, C = 640) over vocabulary sizes -- the
+reference's Spanish wav2vec2 model has a 38-token character vocabulary."""
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.build()
+syn = pkg.synthetic
+DUR = 320.4769 / 16000
+dev = torch.device("cuda:0")
+eng = pkg._native.Engine(0)
+for V in (32, 38, 48, 64, 100):
+    base = [syn.make_segment(s, 3000, V, 22, 28) for s in range(8)]
+    segs = [base[i % 8] for i in range(512)]
+    T = [s[0].shape[0] for s in segs]
+    C = [len(s[1]) for s in segs]
+    U = [len(s[2]) - 1 for s in segs]
+    plan = eng.plan(pkg.CtcSegmentationParameters(index_duration=DUR).to_native(), V, T, C, U)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    d_lpz = t(np.concatenate([s[0].reshape(-1) for s in segs]), np.float32)
+    d_lab = t(np.concatenate([s[1] for s in segs]), np.int32)
+    d_ub = t(np.concatenate([s[2] for s in segs]), np.int32)
+    fol = torch.empty(sum(C), dtype=torch.int32, device=dev)
+    cp = torch.empty(sum(T), dtype=torch.float32, device=dev)
+    seg = torch.empty(3, sum(U), dtype=torch.float64, device=dev)
+    te = torch.empty(512, dtype=torch.int32, device=dev)
+    st = torch.empty(512, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    step = lambda: plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), fol.data_ptr(), cp.data_ptr(), None,
+                                   seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr(), te.data_ptr(), st.data_ptr(), stream)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    plan.set_timing(10)
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    fill, bt = plan.get_timings(10)
+    info = plan.info
+    print(f"V={V}: K={info['cols_per_lane']} stages={info['waves_per_seg']} pitch={info['vocab_pitch']} lds={info['lds_bytes']} "
+          f"fill {np.mean(fill) * 1e3:.0f} us bt {np.mean(bt) * 1e3:.0f} us", flush=True)
+    plan.close()
