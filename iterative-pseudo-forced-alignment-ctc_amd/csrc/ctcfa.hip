@@ -6,6 +6,7 @@
 #include "ctcfa_kernels.hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -168,33 +169,75 @@ int lds_bytes_fill(int W, int VP) {
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
-// Launch-shape heuristic: enough waves to give every SIMD >= 2 (a lone wave issues one
-// VALU per 4 cycles, two share the SIMD at 2), then the widest lane tile (fewest
-// per-row fixed costs), then the least padding.
-bool pick_shape(int B, int Cmax, int VP, int lds_limit, int force_k, int* K_out, int* W_out) {
-    const long target_waves = 2048;
-    double best_score = -1.0;
-    int bestK = 0, bestW = 0;
+// Launch-shape choice from a two-bound cost model of the fill kernel (constants
+// measured with tools/valu_rate.hip, checked against tools/shape_search.py):
+//   a row of a K-column tile costs its wave  n(K) = 9.5 K + 7 instructions;
+//   a wave issues at most one instruction per ~4.7 cycles            -> wave bound  4.7 n
+//   a SIMD retires ~one instruction per 2 cycles for this mix         -> SIMD bound  2 n x (tiles on the
+//                                                                        most loaded SIMD of a CU)
+//   G workgroups share a CU (LDS, wave slots, VGPRs); a batch takes ceil(B / (G x CUs)) rounds.
+// `mixed` reports whether the 8-wave shape (4 heavy + 2 light tiles, 2 heavy + 1 light per SIMD)
+// beats five equal tiles.
+struct ShapeChoice { int K, W; bool mixed; };
+
+int vgprs_of(int K) {  // compiled register counts, rounded up (allocation granule 8)
+    switch (K) {
+        case 1: case 2: return 72;
+        case 3: return 80;
+        case 4: return 88;
+        case 5: return 96;
+        case 6: return 104;
+        case 8: return 128;
+        case 10: return 168;
+        case 12: return 200;
+        default: return 256;
+    }
+}
+
+bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k, bool allow_mixed,
+                ShapeChoice* out) {
+    double best_cost = -1.0;
+    ShapeChoice best{0, 0, false};
+    const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
+    auto instr = [](int K) { return 9.5 * K + 7.0; };
+    auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
+        const int lds = lds_bytes_fill(stages, VP);
+        if (lds > lds_limit) return;
+        const int g_lds = lds_limit / lds;
+        const int g_wave = 32 / waves_per_wg;
+        const int g_vgpr = 4 * (512 / vgprs_of(K)) / waves_per_wg;
+        const int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
+        const int g_eff = std::min(G, wg_per_cu_needed);
+        const int rounds = (wg_per_cu_needed + G - 1) / G;
+        const double wave_bound = 4.7 * instr(K);
+        double simd_bound;
+        if (mixed) {
+            if (g_eff < 2) return;  // the pairing needs two workgroups on a CU
+            simd_bound = 2.0 * (2.0 * instr(K) + instr(K / 2)) * (g_eff / 2.0);
+        } else {
+            // workgroups of 4k waves land evenly on the four SIMDs (the producers rotate); other
+            // sizes leave one SIMD with an extra wave: count the producers as tiles there
+            const double tiles = (waves_per_wg % 4 == 0) ? std::ceil(g_eff * W / 4.0)
+                                                         : std::ceil(g_eff * (W + 1) / 4.0);
+            simd_bound = 2.0 * instr(K) * tiles;
+        }
+        const double pad = (double)(64 * K * W) / (double)Cmax;  // only breaks ties: padding is inside W already
+        const double cost = rounds * std::max(wave_bound, simd_bound) * (1.0 + 1e-3 * pad) + 1e-3 * waves_per_wg;
+        if (best_cost < 0.0 || cost < best_cost) {
+            best_cost = cost;
+            best = {K, W, mixed};
+        }
+    };
     for (int K : kKs) {
         if (force_k && K != force_k) continue;
         const int padded = roundup(Cmax, K);
         const int W = (padded + 64 * K - 1) / (64 * K);
         if (W > 15 || (K >= 10 && W > 4)) continue;  // +1 producer wave; K >= 10 kernels: <= 320 threads
-        if (lds_bytes_fill(W, VP) > lds_limit) continue;
-        const double fill = (double)Cmax / (64.0 * K * W);           // useful lanes
-        const double amort = (9.0 * K) / (9.0 * K + 5.0);             // per-row fixed cost
-        const long waves = (long)B * W;
-        const double occ = std::min(1.0, (double)waves / (double)target_waves);
-        const double score = fill * amort * occ;
-        if (score > best_score) {
-            best_score = score;
-            bestK = K;
-            bestW = W;
-        }
+        consider(K, W, false, W, W + 1);
+        if (!force_k && allow_mixed && W == 5 && (K == 2 || K == 4)) consider(K, W, true, 6, 8);
     }
-    if (!bestK) return false;
-    *K_out = bestK;
-    *W_out = bestW;
+    if (!best.K) return false;
+    *out = best;
     return true;
 }
 
@@ -314,21 +357,15 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         Cmax = std::max(Cmax, (int)C[b]);
         Tmax = std::max(Tmax, (int)T[b]);
     }
-    if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, force_k, &pl->K, &pl->W)) {
+    ShapeChoice shape{0, 0, false};
+    if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"), &shape)) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }
-    // Five equal tiles put 3 compute waves on two SIMDs of a CU and 2 on the others; the mixed
-    // 8-wave shape covers the same 320*K columns with 2 heavy + 1 light tile on every SIMD.
-    // Taken when the caller did not force a tile width and there are workgroups to pair up.
-    pl->KL = pl->K;
-    if (force_k == 0 && pl->W == 5 && (pl->K == 2 || pl->K == 4) && batch >= eng->num_cu &&
-        !std::getenv("CTCFA_NO_MIXED") && lds_bytes_fill(6, pl->VP) * 2 <= eng->lds_limit) {
-        pl->KL = pl->K / 2;
-        pl->roles = mixed8_roles(pl->K, pl->KL);
-    } else {
-        pl->roles = uniform_roles(pl->K, pl->W);
-    }
+    pl->K = shape.K;
+    pl->W = shape.W;
+    pl->KL = shape.mixed ? shape.K / 2 : shape.K;
+    pl->roles = shape.mixed ? mixed8_roles(pl->K, pl->KL) : uniform_roles(pl->K, pl->W);
     pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP);
     if (!pl->fill_fn) {
         delete pl;

@@ -162,20 +162,14 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
         // waves (registers double-buffered), so HBM latency never sits inside a step.
         constexpr int PASSES = kRows * VP / 64;
-        // VP <= 64: the whole block travels in registers (two sets, swapped by 2x unrolling)
-        constexpr int CH = (VP <= 64) ? PASSES : 16;  // loads in flight per chunk
+        constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
         bool notneg = false;  // any staged emission that is not <= 0 (NaN counts)
         auto publish_flag = [&]() {
             if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
         };
-        auto load_chunk = [&](int jb, int p0, float (&e)[CH], float& lbv) {
+        auto load_chunk = [&](int jb, int p0, float (&e)[CH]) {
             const int t0 = jb * kRows + 1;
-            if constexpr (VP <= 64) {  // lane r < 32 fetches the blank entry of row r of the block
-                int tb = t0 + (lane & 31);
-                tb = tb < T ? tb : T - 1;
-                lbv = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tb * V + blank) * 4u);
-            }
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 const int idx = (p0 + q) * 64 + lane;  // element of the block
@@ -186,7 +180,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 e[q] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V + svc) * 4u);
             }
         };
-        auto write_chunk = [&](int jb, int p0, const float (&e)[CH], float lbv) {
+        auto write_chunk = [&](int jb, int p0, const float (&e)[CH]) {
             unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
             const int t0 = jb * kRows + 1;
 #pragma unroll
@@ -196,8 +190,10 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const int r = idx / VP;
                 const int t = t0 + r;
                 float lb;
-                if constexpr (VP <= 64) {  // the row's blank entry sits in lane r of lbv
-                    lb = __shfl(lbv, r);
+                if constexpr (VP == 32) {  // two rows per pass: the row's blank entry via readlane
+                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), blank));
+                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[q]), 32 + blank));
+                    lb = (lane < 32) ? lo : hi;
                 } else {
                     const int tc = t < T ? t : T - 1;
                     lb = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(tc * V + blank) * 4u);
@@ -305,38 +301,36 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     *reinterpret_cast<float2*>(dst + r * (PITCH * 8)) = v;
                 }
             };
-            float ea[kRows], eb[kRows];
+            // One register set: the loads of block s+2 are issued right after block s+1 has been
+            // written and have a whole step (~3 us) to arrive.  (A second set would cost 32 VGPRs
+            // of every wave of the kernel, i.e. the room the overlapped backtrack kernel lives in.)
+            float ea[kRows];
             rload(0, ea);
             rwrite(0, ea);
             publish_flag();
             if (1 < nblk) rload(1, ea);
             lds_barrier();
-            for (int s = 0; s < nsteps; s += 2) {
-                if (s + 2 < nblk) rload(s + 2, eb);
+            for (int s = 0; s < nsteps; ++s) {
                 if (s + 1 < nblk) { rwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
-                lds_barrier();
-                if (s + 1 >= nsteps) break;
-                if (s + 3 < nblk) rload(s + 3, ea);
-                if (s + 2 < nblk) { rwrite(s + 2, eb); publish_flag(); }
+                if (s + 2 < nblk) rload(s + 2, ea);
                 lds_barrier();
             }
         } else if constexpr (PASSES == CH) {
 
             // whole block in one chunk (VP == 32): two register sets, swapped by 2x unrolling
             float ea[CH], eb[CH];
-            float la = 0.0f, lbb = 0.0f;
-            load_chunk(0, 0, ea, la);
-            write_chunk(0, 0, ea, la);
+            load_chunk(0, 0, ea);
+            write_chunk(0, 0, ea);
             publish_flag();
-            if (1 < nblk) load_chunk(1, 0, ea, la);
+            if (1 < nblk) load_chunk(1, 0, ea);
             lds_barrier();
             for (int s = 0; s < nsteps; s += 2) {
-                if (s + 2 < nblk) load_chunk(s + 2, 0, eb, lbb);
-                if (s + 1 < nblk) { write_chunk(s + 1, 0, ea, la); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
+                if (s + 2 < nblk) load_chunk(s + 2, 0, eb);
+                if (s + 1 < nblk) { write_chunk(s + 1, 0, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
                 lds_barrier();
                 if (s + 1 >= nsteps) break;
-                if (s + 3 < nblk) load_chunk(s + 3, 0, ea, la);
-                if (s + 2 < nblk) { write_chunk(s + 2, 0, eb, lbb); publish_flag(); }
+                if (s + 3 < nblk) load_chunk(s + 3, 0, ea);
+                if (s + 2 < nblk) { write_chunk(s + 2, 0, eb); publish_flag(); }
                 lds_barrier();
             }
         } else {
@@ -345,9 +339,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             auto stage_block = [&](int jb) {
 #pragma unroll 1
                 for (int p0 = 0; p0 < PASSES; p0 += CH) {
-                    float unused = 0.0f;
-                    load_chunk(jb, p0, e, unused);
-                    write_chunk(jb, p0, e, unused);
+                    load_chunk(jb, p0, e);
+                    write_chunk(jb, p0, e);
                 }
                 publish_flag();
             };
