@@ -65,6 +65,12 @@ def patch_F(k, h):
     return k, h
 
 
+def patch_P(k, h):
+    """backtrack kernel at wave priority 3 (above the fill kernel's 1/2)"""
+    k = sub(k, "    if (sd.prestatus == kPreWindowed) return;  // windowed_kernel owns this segment", "    __builtin_amdgcn_s_setprio(3);\n    if (sd.prestatus == kPreWindowed) return;")
+    return k, h
+
+
 def patch_stamp(k, h):
     stamp_def = """
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(seg_lastcol);
@@ -105,7 +111,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
