@@ -286,13 +286,15 @@ def test_full_size_properties(pkg, engine):
     plan.close()
 
 
-def test_pipelined_runs_match_serial(pkg, engine):
+@pytest.mark.parametrize("min_window", [8000, 256])
+def test_pipelined_runs_match_serial(pkg, engine, min_window):
     """ctcfa_plan_run_pipelined (backtrack on the plan's side stream, two workspaces) must give
-    the results of the serial entry for every call in a sequence."""
+    the results of the serial entry for every call in a sequence.  min_window 256 sends every
+    segment (T = 700) through the windowed kernel, which shares ONE table workspace between runs."""
     import torch
     syn = pkg.synthetic
     batches = [[syn.make_segment(50 * k + s, 700, 32, 5, 24) for s in range(16)] for k in range(4)]
-    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    config = pkg.CtcSegmentationParameters(index_duration=DUR, min_window_size=min_window)
     T, C, U = [700] * 16, [len(batches[0][0][1])] * 16, [5] * 16
     plan = engine.plan(config.to_native(), 32, T, C, U)
     dev = torch.device("cuda:0")
