@@ -98,7 +98,9 @@ void ctcfa_default_params(ctcfa_params* p); /* CtcSegmentationParameters default
  * no utterance scoring).  Replaces the per-call shape handling of
  * ctc_segmentation(): the `len(ground_truth) > lpz.shape[0]` assertion and the
  * `min(window_size, lpz.shape[0])` window decision become per-segment status.
- * force_cols_per_lane: 0 = heuristic, else K in {1,2,3,4,5,6,8,10,12,16}.
+ * force_cols_per_lane: 0 = launch-shape model, else K in {1,2,3,4,5,6,8,10,12,16}.
+ * vocab <= 128: LDS-staged fill kernel.  vocab > 128 (sub-word models): gather kernel; needs
+ * CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO and C <= 961, else CTCFA_ERR_UNSUPPORTED.
  */
 int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params,
                       int32_t batch, int32_t vocab, const int32_t* T, const int32_t* C,

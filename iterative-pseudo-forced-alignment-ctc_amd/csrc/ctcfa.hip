@@ -58,6 +58,7 @@ struct ctcfa_plan {
     int32_t* d_win_offs = nullptr;
     int64_t win_table_floats = 0, win_cols = 0;
     int lds_win = 0;
+    bool gather = false;              // wide vocabulary: fill_gather_kernel
     int KL = 0;                       // columns per lane of the light tiles (== K for uniform shapes)
     ctcfa::FillRoles roles{};         // what each wave of a fill workgroup does
     ctcfa::FillRoles* d_roles = nullptr;
@@ -334,7 +335,11 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero (gratis_blank) is not supported yet");
     if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > 128)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1,128]");
-    if (vocab > 128) return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128 (token-level vocabularies) not supported yet");
+    // wide vocabularies (sub-word models) take the gather kernel: no LDS staging of vocabulary rows
+    const bool gather = vocab > 128 || std::getenv("CTCFA_FORCE_GATHER") != nullptr;
+    if (gather && !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO))
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED,
+                       "vocab > 128 needs preamble_transition_cost_zero (the package default)");
     HIP_TRY(eng, hipSetDevice(eng->device));
 
     ctcfa_plan* pl = new ctcfa_plan();
@@ -357,8 +362,16 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         Cmax = std::max(Cmax, (int)C[b]);
         Tmax = std::max(Tmax, (int)T[b]);
     }
+    pl->gather = gather;
     ShapeChoice shape{0, 0, false};
-    if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"), &shape)) {
+    if (gather) {
+        const int W = std::max(1, (Cmax - 1 + 63) / 64);  // label columns 1 .. C-1, one per lane
+        if (W > 15) {
+            delete pl;
+            return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128: at most 961 label columns per segment");
+        }
+        shape = {1, W, false};
+    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"), &shape)) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }
@@ -366,6 +379,10 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     pl->W = shape.W;
     pl->KL = shape.mixed ? shape.K / 2 : shape.K;
     pl->roles = shape.mixed ? mixed8_roles(pl->K, pl->KL) : uniform_roles(pl->K, pl->W);
+    if (gather) {  // W compute waves, no producer
+        pl->roles.nwaves = pl->W;
+        pl->roles.wave[pl->W] = {ctcfa::kRoleIdle, 0, 0};
+    }
     pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP);
     if (!pl->fill_fn) {
         delete pl;
@@ -373,7 +390,8 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
     }
     const int K = pl->K;
     const int64_t Cpad = pl->roles.cpad;
-    pl->lds_fill = lds_bytes_fill(pl->roles.nstages, pl->VP);
+    pl->lds_fill = gather ? (pl->W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + ctcfa::kSinkBytes
+                          : lds_bytes_fill(pl->roles.nstages, pl->VP);
     // tile that holds padded column pc
     auto tile_of = [&](int pc, int* tk, int* tbase, int* tstage) {
         for (int w = 0; w < pl->roles.nwaves; ++w) {
@@ -399,7 +417,11 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
         s.T = T[b];
         s.C = C[b];
         s.U = U ? U[b] : 0;
-        {   // left padding: the last label column must sit at k == K-1 of its lane
+        if (gather) {  // padded column pc holds label column pc + 1 (column 0 is not a DP column)
+            s.shift = -1;
+            s.owner_stage = (C[b] - 2) / 64;
+            s.owner_lane = (C[b] - 2) % 64;
+        } else {   // left padding: the last label column must sit at k == K-1 of its lane
             int tk = K, tbase = 0, tstage = 0;
             (void)tile_of(C[b] - 1, &tk, &tbase, &tstage);
             s.shift = (tk - 1) - ((C[b] - 1 - tbase) % tk);   // stays inside the same lane, hence the same tile
@@ -549,6 +571,13 @@ int check_args(ctcfa_plan* pl, const RunArgs& a, bool* want_seg) {
 }
 
 int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st) {
+    if (pl->gather) {
+        hipLaunchKernelGGL(ctcfa::fill_gather_kernel, dim3(pl->B), dim3(64 * pl->W), pl->lds_fill, st, pl->d_segs,
+                           a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
+                           pl->roles.cpad);
+        HIP_TRY(pl->eng, hipGetLastError());
+        return CTCFA_OK;
+    }
     hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, pl->d_segs, a.d_lpz,
                        a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
                        (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0, pl->d_roles);

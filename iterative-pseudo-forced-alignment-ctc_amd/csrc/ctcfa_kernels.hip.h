@@ -530,6 +530,146 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 }
 
 // ---------------------------------------------------------------------------------------
+// Fill kernel for wide vocabularies (V > 128: sub-word CTC models).  A vocabulary row no longer
+// fits an LDS ring, so nothing is staged: every lane owns ONE label column (K = 1) and gathers
+// its own emission lpz[t, g_c] straight from HBM/L2, one 32-row block ahead of its use (two
+// register sets, alternating blocks); the blank entry of the block's rows rides in lanes 0..31
+// and reaches the row loop through v_readlane.  No producer wave, hence no posflag: only the
+// input-independent dead-zone skip is kept.  Column 0 of the trellis is not a DP column here:
+// with preamble_transition_cost_zero it is identically 0 and simply pre-fills the boundary ring
+// of stage 0 (SegDesc.shift == -1: padded column pc holds label column pc + 1).
+// Same recurrence, decisions, boundary exchange and decision-word layout as fill_kernel.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+fill_gather_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
+                   const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
+                   float* __restrict__ lastcol, int V, int blank, int Cpad) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = blockDim.x >> 6;
+    const SegDesc sd = segs[blockIdx.x];
+    if (sd.prestatus != 0) return;  // uniform
+    const int T = sd.T, C = sd.C;
+    const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(lpz + sd.lpz_off);
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
+    const uint32_t bnd_base = 0u;
+    const uint32_t lcring_base = static_cast<uint32_t>((W + 1) * kBndPitch * 4);
+    const uint32_t sink_base = lcring_base + 64 * 4;
+    float* bnd = reinterpret_cast<float*>(smem);
+    const int nblk = (T - 1 + kRows - 1) / kRows;
+    const int nsteps = nblk + W - 1;
+    // ring 0 = trellis column 0 (table[t,0] == 0 with the preamble flag), rings 1.. = -1e9
+    for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = (i < kBndPitch) ? 0.0f : kProbMax;
+
+    const int pc = w * 64 + lane;
+    const int c = pc + 1;  // shift == -1
+    const uint32_t goff = static_cast<uint32_t>((c < C) ? seg_lab[c] : blank) * 4u;
+    float prev = kProbMax;  // table[0, c >= 1]
+    uint32_t dec = 0u;
+    const int wstar = sd.owner_stage;
+    const int lstar = sd.owner_lane;
+    float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);
+    lds_barrier();
+    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+
+    int jlast = nblk - 1;  // dead zone, as in fill_kernel
+    {
+        const int cmax = w * 64 + 64;  // label column of lane 63
+        if (cmax < C - 1) {
+            const int tdead = T - C + cmax;
+            jlast = tdead >= 1 ? (tdead - 1) / kRows : -1;
+            if (jlast > nblk - 1) jlast = nblk - 1;
+        }
+    }
+    if (w > wstar) jlast = -1;
+
+    auto gload = [&](int jb, float (&e)[kRows], float& lbv) {
+        const int t0 = jb * kRows + 1;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            int t = t0 + r;
+            t = t < T ? t : T - 1;  // rows past the end: re-read, results unused
+            e[r] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint64_t>(t) * static_cast<uint64_t>(V) * 4u + goff);
+        }
+        int tb = t0 + (lane & 31);
+        tb = tb < T ? tb : T - 1;
+        lbv = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint64_t>(tb) * static_cast<uint64_t>(V) * 4u +
+                                              static_cast<uint32_t>(blank) * 4u);
+    };
+    auto block = [&](int j, const float (&e)[kRows], float lbv) {
+        const int q = j & 3;
+        const uint32_t in_addr = bnd_base + static_cast<uint32_t>((w * kBndPitch + q * kRows) * 4);
+        uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 16);
+        if (w == wstar) {
+            if (lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
+        } else if (lane == 63 && w < wstar) {
+            out_addr = bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows) * 4);
+        }
+        float4 lin4 = *reinterpret_cast<const float4*>(smem + in_addr);
+        float4 lin4_next = lin4;
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            if (i % 4 == 0) {
+                if (i > 0) lin4 = lin4_next;
+                if (i + 4 < kRows) lin4_next = *reinterpret_cast<const float4*>(smem + in_addr + (i + 4) * 4);
+            }
+            const float lin = (i % 4 == 0) ? lin4.x : (i % 4 == 1) ? lin4.y : (i % 4 == 2) ? lin4.z : lin4.w;
+            const float pl = dpp_wave_shr1(lin, prev);
+            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbv), i));
+            const float ee = e[i];
+            const float m = max3f(lb, ee, kProbMax);
+            const float a = pl + ee;
+            const float b = prev + m;
+            const float nw = max3f(a, b, kProbMax);
+            const float rsw = ee - (nw - pl);
+            const float rst = m - (nw - prev);
+            const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+            dec = __builtin_amdgcn_alignbit(dec, __float_as_uint(d), 31);
+            prev = nw;
+            if ((i + 1) % 4 == 0) pub4.x = prev;
+            else if ((i + 1) % 4 == 1) pub4.y = prev;
+            else if ((i + 1) % 4 == 2) pub4.z = prev;
+            else {
+                pub4.w = prev;
+                *reinterpret_cast<float4*>(smem + out_addr + (i - 2) * 4) = pub4;
+            }
+            asm volatile("" : "+v"(dec));
+        }
+        bits[sd.bits_off + (int64_t)j * Cpad + pc] = dec;
+        if (w == wstar) {
+            const int t = j * kRows + lane;
+            if (lane < kRows && t >= 1 && t < T)
+                seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
+        }
+        if (j == jlast && jlast < nblk - 1 && lane == 63 && w < wstar)
+            bnd[(w + 1) * kBndPitch + ((j + 1) * kRows) % kBnd] = pub4.x;
+    };
+
+    for (int i = 0; i < w; ++i) lds_barrier();  // stage w starts w steps late
+    float ea[kRows], eb[kRows];
+    float la = 0.0f, lbb = 0.0f;
+    if (0 <= jlast) gload(0, ea, la);
+    int done = 0;
+    for (int j = 0; j < nblk; j += 2) {
+        if (j + 1 <= jlast) gload(j + 1, eb, lbb);
+        if (j <= jlast) block(j, ea, la);
+        lds_barrier();
+        ++done;
+        if (j + 1 >= nblk) break;
+        if (j + 2 <= jlast) gload(j + 2, ea, la);
+        if (j + 1 <= jlast) block(j + 1, eb, lbb);
+        lds_barrier();
+        ++done;
+    }
+    for (int i = w + done; i < nsteps; ++i) lds_barrier();
+    if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;
+}
+
+// ---------------------------------------------------------------------------------------
 // Backtrack + per-frame outputs + utterance scoring.  grid = B, block = kBtThreads (4 waves).
 //   phase 0  end cell: first maximum of the last column            (all threads)
 //   phase A  the walk: one scalar step per run of STAYs            (wave 0; others wait)

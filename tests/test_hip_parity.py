@@ -651,3 +651,43 @@ def test_mixed_shape_with_four_column_heavy_tiles(pkg, oracle, engine):
     for i in range(3, len(segs)):
         assert np.array_equal(res[i]["frame_of_label"], res[i % 3]["frame_of_label"])
         assert np.array_equal(res[i]["seg_score"], res[i % 3]["seg_score"])
+
+
+@pytest.mark.parametrize("V,blank", [(129, 0), (500, 0), (1000, 37), (4096, 4095)])
+def test_wide_vocabularies_take_the_gather_kernel(pkg, oracle, V, blank):
+    """V > 128 (sub-word CTC models): no LDS staging of vocabulary rows, every lane gathers its
+    own column's emission.  Ragged batch incl. a segment with T < C and one with C = 2."""
+    rng = np.random.default_rng(10_000 + V)
+    segs = []
+    for s in range(12):
+        U = int(rng.integers(0, 7)) if s else 0
+        n = int(rng.integers(3, 40))
+        gt, ub = pkg.synthetic.make_labels(rng, U, n, V, blank=blank)
+        C = len(gt)
+        T = C - 2 if s == 3 else int(rng.integers(C, 4 * C + 60))
+        T = max(T, 2)
+        if s % 3 == 0:
+            lpz = pkg.synthetic.make_emissions(rng, T, V, gt, blank=blank)
+        elif s % 3 == 1:
+            x = rng.standard_normal((T, V)) * 2
+            lpz = (x - np.log(np.exp(x).sum(1, keepdims=True))).astype(np.float32)
+        else:
+            lpz = (np.round(rng.uniform(-9, 0, size=(T, V)) * 2) / 2).astype(np.float32)
+        segs.append((lpz, gt, ub))
+    for kw in (dict(blank=blank), dict(blank=blank, backtrack_from_max_t=True, score_min_mean_over_L=7)):
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+
+
+def test_wide_vocabulary_long_label_sequences(pkg, oracle):
+    """Up to 961 label columns (15 waves x 64 lanes) and the windowed regime with V = 300."""
+    rng = np.random.default_rng(10_500)
+    segs = []
+    for U, n, T in ((7, 136, 2500), (20, 40, 1000), (6, 20, 300)):
+        gt, ub = pkg.synthetic.make_labels(rng, U, n, 300)
+        segs.append((pkg.synthetic.make_emissions(rng, T, 300, gt), gt, ub))
+    assert max(len(s[1]) for s in segs) == 961
+    _check(pkg, oracle, segs, _run(pkg, segs))
+    kw = dict(min_window_size=200, max_window_size=5000)
+    _check(pkg, oracle, segs[1:], _run(pkg, segs[1:], **kw), cfg_kw=kw)
+    with pytest.raises(NotImplementedError):
+        _run(pkg, segs, preamble_transition_cost_zero=False)
