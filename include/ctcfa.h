@@ -87,7 +87,9 @@ typedef struct ctcfa_plan_info {
 int ctcfa_version(void);
 const char* ctcfa_status_string(int status);
 
-/* Engine.  device >= 0 selects the HIP device. */
+/* Engine.  device >= 0 selects the HIP device.  One call at a time per engine: it owns a HIP
+ * stream and a grow-only device scratch that ctcfa_align_batch reuses from call to call (the
+ * reference runs one alignment process per worker: align_utterances.sh:127-137). */
 int ctcfa_engine_create(ctcfa_engine** out, int device);
 void ctcfa_engine_destroy(ctcfa_engine* eng);
 const char* ctcfa_last_error(const ctcfa_engine* eng);

@@ -18,12 +18,23 @@
 using ctcfa::BtParams;
 using ctcfa::SegDesc;
 
+// Grow-only device scratch of the host-buffer entry (ctcfa_align_batch is synchronous, so one
+// call's buffers are free again when the next one starts): an anchor iteration issues hundreds
+// of small calls and would otherwise pay ~15 hipMalloc/hipFree pairs in each.
+struct ScratchSlot {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+enum { kSlotLpz, kSlotLab, kSlotFol, kSlotCp, kSlotState, kSlotTend, kSlotStatus, kSlotUb, kSlotSeg,
+       kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kNumSlots };
+
 struct ctcfa_engine {
     int device = -1;
     hipStream_t stream = nullptr;
     std::string err;
     int lds_limit = 160 * 1024;
     int num_cu = 256;
+    ScratchSlot scratch[kNumSlots];
 };
 
 struct ctcfa_plan {
@@ -35,6 +46,7 @@ struct ctcfa_plan {
     std::vector<SegDesc> segs;
     int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
     SegDesc* d_segs = nullptr;
+    bool scratch_owned = false;  // d_segs / d_roles / d_bits[0] / d_lastcol[0] live in the engine's scratch
     // workspace [2]: index 1 exists only once the pipelined entry has been used
     uint32_t* d_bits[2] = {nullptr, nullptr};
     float* d_lastcol[2] = {nullptr, nullptr};
@@ -298,6 +310,8 @@ int ctcfa_engine_create(ctcfa_engine** out, int device) {
 
 void ctcfa_engine_destroy(ctcfa_engine* eng) {
     if (!eng) return;
+    for (auto& sl : eng->scratch)
+        if (sl.p) (void)hipFree(sl.p);
     if (eng->stream) (void)hipStreamDestroy(eng->stream);
     delete eng;
 }
@@ -306,6 +320,12 @@ const char* ctcfa_last_error(const ctcfa_engine* eng) { return eng ? eng->err.c_
 
 void ctcfa_plan_destroy(ctcfa_plan* plan) {
     if (!plan) return;
+    if (plan->scratch_owned) {
+        plan->d_segs = nullptr;
+        plan->d_roles = nullptr;
+        plan->d_bits[0] = nullptr;
+        plan->d_lastcol[0] = nullptr;
+    }
     if (plan->d_segs) (void)hipFree(plan->d_segs);
     if (plan->d_roles) (void)hipFree(plan->d_roles);
     if (plan->d_win_list) (void)hipFree(plan->d_win_list);
@@ -323,9 +343,30 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
     delete plan;
 }
 
-int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
-                      int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
-                      int32_t force_k) {
+}  // extern "C"
+
+namespace {
+
+hipError_t scratch_get(ctcfa_engine* eng, int slot, void** p, size_t bytes) {
+    ScratchSlot& sl = eng->scratch[slot];
+    if (sl.cap < bytes) {
+        if (sl.p) (void)hipFree(sl.p);
+        sl.p = nullptr;
+        sl.cap = 0;
+        const size_t cap = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&sl.p, cap);
+        if (e != hipSuccess) return e;
+        sl.cap = cap;
+    }
+    *p = sl.p;
+    return hipSuccess;
+}
+
+// use_scratch: the plan lives for one synchronous ctcfa_align_batch call; its device tables and
+// workspace come from the engine's grow-only scratch and the uploads go onto the engine's stream
+int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
+                     int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
+                     int32_t force_k, bool use_scratch) {
     if (!eng || !out || !params || !T || !C) return set_err(eng, CTCFA_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (batch <= 0 || vocab <= 0) return set_err(eng, CTCFA_ERR_INVALID, "batch and vocab must be positive");
@@ -489,12 +530,25 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
             return set_err(eng, _e == hipErrorOutOfMemory ? CTCFA_ERR_NOMEM : CTCFA_ERR_HIP, m); \
         }                                                                                     \
     } while (0)
-    PLAN_TRY(hipMalloc(&pl->d_roles, sizeof(ctcfa::FillRoles)));
-    PLAN_TRY(hipMemcpy(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice));
-    PLAN_TRY(hipMalloc(&pl->d_segs, sizeof(SegDesc) * (size_t)batch));
-    PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
-    PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
-    PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+    if (use_scratch) {
+        pl->scratch_owned = true;
+        PLAN_TRY(scratch_get(eng, kSlotRoles, reinterpret_cast<void**>(&pl->d_roles), sizeof(ctcfa::FillRoles)));
+        PLAN_TRY(scratch_get(eng, kSlotSegs, reinterpret_cast<void**>(&pl->d_segs), sizeof(SegDesc) * (size_t)batch));
+        PLAN_TRY(scratch_get(eng, kSlotBits, reinterpret_cast<void**>(&pl->d_bits[0]),
+                             sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
+        PLAN_TRY(scratch_get(eng, kSlotLastcol, reinterpret_cast<void**>(&pl->d_lastcol[0]),
+                             sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+        PLAN_TRY(hipMemcpyAsync(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice, eng->stream));
+        PLAN_TRY(hipMemcpyAsync(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice,
+                                eng->stream));
+    } else {
+        PLAN_TRY(hipMalloc(&pl->d_roles, sizeof(ctcfa::FillRoles)));
+        PLAN_TRY(hipMemcpy(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice));
+        PLAN_TRY(hipMalloc(&pl->d_segs, sizeof(SegDesc) * (size_t)batch));
+        PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
+        PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
+        PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+    }
     if (pl->lds_fill > 48 * 1024)
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
@@ -514,6 +568,16 @@ int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* p
 #undef PLAN_TRY
     *out = pl;
     return CTCFA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
+                      int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
+                      int32_t force_k) {
+    return plan_create_impl(eng, out, params, batch, vocab, T, C, U, force_k, false);
 }
 
 int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
@@ -735,7 +799,7 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
     ctcfa_plan* pl = nullptr;
-    int rc = ctcfa_plan_create(eng, &pl, params, batch, vocab, T, C, U, 0);
+    int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true);
     if (rc != CTCFA_OK) return rc;
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
     const size_t n_lpz = (size_t)pl->total_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
@@ -744,12 +808,11 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     int32_t *d_lab = nullptr, *d_ub = nullptr, *d_fol = nullptr, *d_state = nullptr, *d_tend = nullptr, *d_status = nullptr;
     double* d_seg = nullptr;
     hipStream_t st = eng->stream;
-    auto cleanup = [&]() {
-        (void)hipFree(d_lpz); (void)hipFree(d_cp); (void)hipFree(d_lab); (void)hipFree(d_ub);
-        (void)hipFree(d_fol); (void)hipFree(d_state); (void)hipFree(d_tend); (void)hipFree(d_status);
-        (void)hipFree(d_seg);
+    auto cleanup = [&]() {  // the buffers are the engine's scratch; quiesce before the next call reuses them
+        (void)hipStreamSynchronize(st);
         ctcfa_plan_destroy(pl);
     };
+#define SCRATCH(slot, ptr, bytes) scratch_get(eng, slot, reinterpret_cast<void**>(&ptr), bytes)
 #define AB_TRY(expr)                                                                      \
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \
@@ -759,16 +822,16 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
             return set_err(eng, CTCFA_ERR_HIP, m);                                        \
         }                                                                                 \
     } while (0)
-    AB_TRY(hipMalloc(&d_lpz, n_lpz * sizeof(float)));
-    AB_TRY(hipMalloc(&d_lab, n_lab * sizeof(int32_t)));
-    AB_TRY(hipMalloc(&d_fol, n_lab * sizeof(int32_t)));
-    AB_TRY(hipMalloc(&d_cp, n_frm * sizeof(float)));
-    if (state) AB_TRY(hipMalloc(&d_state, n_frm * sizeof(int32_t)));
-    AB_TRY(hipMalloc(&d_tend, batch * sizeof(int32_t)));
-    AB_TRY(hipMalloc(&d_status, batch * sizeof(int32_t)));
+    AB_TRY(SCRATCH(kSlotLpz, d_lpz, n_lpz * sizeof(float)));
+    AB_TRY(SCRATCH(kSlotLab, d_lab, n_lab * sizeof(int32_t)));
+    AB_TRY(SCRATCH(kSlotFol, d_fol, n_lab * sizeof(int32_t)));
+    AB_TRY(SCRATCH(kSlotCp, d_cp, n_frm * sizeof(float)));
+    if (state) AB_TRY(SCRATCH(kSlotState, d_state, n_frm * sizeof(int32_t)));
+    AB_TRY(SCRATCH(kSlotTend, d_tend, batch * sizeof(int32_t)));
+    AB_TRY(SCRATCH(kSlotStatus, d_status, batch * sizeof(int32_t)));
     if (want_seg) {
-        AB_TRY(hipMalloc(&d_ub, n_ub * sizeof(int32_t)));
-        AB_TRY(hipMalloc(&d_seg, 3 * n_utt * sizeof(double)));
+        AB_TRY(SCRATCH(kSlotUb, d_ub, n_ub * sizeof(int32_t)));
+        AB_TRY(SCRATCH(kSlotSeg, d_seg, 3 * n_utt * sizeof(double)));
         AB_TRY(hipMemcpyAsync(d_ub, utt_begin, n_ub * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
     AB_TRY(hipMemcpyAsync(d_lpz, lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
@@ -792,6 +855,7 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     }
     AB_TRY(hipStreamSynchronize(st));
 #undef AB_TRY
+#undef SCRATCH
     cleanup();
     return CTCFA_OK;
 }
