@@ -25,8 +25,7 @@ struct ScratchSlot {
     void* p = nullptr;
     size_t cap = 0;
 };
-enum { kSlotLpz, kSlotLab, kSlotFol, kSlotCp, kSlotState, kSlotTend, kSlotStatus, kSlotUb, kSlotSeg,
-       kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kNumSlots };
+enum { kSlotLpz, kSlotIn, kSlotOut, kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kNumSlots };
 
 struct ctcfa_engine {
     int device = -1;
@@ -35,6 +34,7 @@ struct ctcfa_engine {
     int lds_limit = 160 * 1024;
     int num_cu = 256;
     ScratchSlot scratch[kNumSlots];
+    std::vector<unsigned char> host_out;  // staging for the single result download of ctcfa_align_batch
 };
 
 struct ctcfa_plan {
@@ -804,15 +804,11 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
     const size_t n_lpz = (size_t)pl->total_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
     const size_t n_utt = (size_t)pl->total_U, n_ub = n_utt + batch;
-    float *d_lpz = nullptr, *d_cp = nullptr;
-    int32_t *d_lab = nullptr, *d_ub = nullptr, *d_fol = nullptr, *d_state = nullptr, *d_tend = nullptr, *d_status = nullptr;
-    double* d_seg = nullptr;
     hipStream_t st = eng->stream;
     auto cleanup = [&]() {  // the buffers are the engine's scratch; quiesce before the next call reuses them
         (void)hipStreamSynchronize(st);
         ctcfa_plan_destroy(pl);
     };
-#define SCRATCH(slot, ptr, bytes) scratch_get(eng, slot, reinterpret_cast<void**>(&ptr), bytes)
 #define AB_TRY(expr)                                                                      \
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \
@@ -822,41 +818,52 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
             return set_err(eng, CTCFA_ERR_HIP, m);                                        \
         }                                                                                 \
     } while (0)
-    AB_TRY(SCRATCH(kSlotLpz, d_lpz, n_lpz * sizeof(float)));
-    AB_TRY(SCRATCH(kSlotLab, d_lab, n_lab * sizeof(int32_t)));
-    AB_TRY(SCRATCH(kSlotFol, d_fol, n_lab * sizeof(int32_t)));
-    AB_TRY(SCRATCH(kSlotCp, d_cp, n_frm * sizeof(float)));
-    if (state) AB_TRY(SCRATCH(kSlotState, d_state, n_frm * sizeof(int32_t)));
-    AB_TRY(SCRATCH(kSlotTend, d_tend, batch * sizeof(int32_t)));
-    AB_TRY(SCRATCH(kSlotStatus, d_status, batch * sizeof(int32_t)));
-    if (want_seg) {
-        AB_TRY(SCRATCH(kSlotUb, d_ub, n_ub * sizeof(int32_t)));
-        AB_TRY(SCRATCH(kSlotSeg, d_seg, 3 * n_utt * sizeof(double)));
-        AB_TRY(hipMemcpyAsync(d_ub, utt_begin, n_ub * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
+    // Device layout: emissions on their own; the small inputs (labels, utt_begin) in ONE upload;
+    // every result array in ONE block that comes back with ONE download (a copy call costs ~10 us,
+    // more than the kernels of a 10 s window).
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t in_lab = 0, in_ub = up(n_lab * 4), in_bytes = in_ub + (want_seg ? up(n_ub * 4) : 0);
+    const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
+                 o_tend = o_state + (state ? up(n_frm * 4) : 0), o_status = o_tend + up((size_t)batch * 4),
+                 o_seg = o_status + up((size_t)batch * 4), out_bytes = o_seg + (want_seg ? up(3 * n_utt * 8) : 0);
+    float* d_lpz = nullptr;
+    unsigned char *d_in = nullptr, *d_out = nullptr;
+    AB_TRY(scratch_get(eng, kSlotLpz, reinterpret_cast<void**>(&d_lpz), n_lpz * sizeof(float)));
+    AB_TRY(scratch_get(eng, kSlotIn, reinterpret_cast<void**>(&d_in), in_bytes));
+    AB_TRY(scratch_get(eng, kSlotOut, reinterpret_cast<void**>(&d_out), out_bytes));
+    if (eng->host_out.size() < std::max(in_bytes, out_bytes)) eng->host_out.resize(std::max(in_bytes, out_bytes) * 5 / 4 + 256);
+    unsigned char* h = eng->host_out.data();
+    std::memcpy(h + in_lab, labels, n_lab * 4);
+    if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
+    AB_TRY(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, st));
     AB_TRY(hipMemcpyAsync(d_lpz, lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
-    AB_TRY(hipMemcpyAsync(d_lab, labels, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    rc = ctcfa_plan_run_device(pl, d_lpz, d_lab, d_ub, d_fol, d_cp, d_state, d_seg,
-                               d_seg ? d_seg + n_utt : nullptr, d_seg ? d_seg + 2 * n_utt : nullptr, d_tend,
-                               d_status, st);
+    int32_t* d_lab = reinterpret_cast<int32_t*>(d_in + in_lab);
+    int32_t* d_ub = want_seg ? reinterpret_cast<int32_t*>(d_in + in_ub) : nullptr;
+    double* d_seg = want_seg ? reinterpret_cast<double*>(d_out + o_seg) : nullptr;
+    rc = ctcfa_plan_run_device(pl, d_lpz, d_lab, d_ub, reinterpret_cast<int32_t*>(d_out + o_fol),
+                               reinterpret_cast<float*>(d_out + o_cp),
+                               state ? reinterpret_cast<int32_t*>(d_out + o_state) : nullptr, d_seg,
+                               d_seg ? d_seg + n_utt : nullptr, d_seg ? d_seg + 2 * n_utt : nullptr,
+                               reinterpret_cast<int32_t*>(d_out + o_tend), reinterpret_cast<int32_t*>(d_out + o_status), st);
     if (rc != CTCFA_OK) {
         cleanup();
         return rc;
     }
-    AB_TRY(hipMemcpyAsync(frame_of_label, d_fol, n_lab * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AB_TRY(hipMemcpyAsync(char_prob, d_cp, n_frm * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (state) AB_TRY(hipMemcpyAsync(state, d_state, n_frm * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AB_TRY(hipMemcpyAsync(t_end, d_tend, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AB_TRY(hipMemcpyAsync(status, d_status, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (want_seg) {
-        AB_TRY(hipMemcpyAsync(seg_start, d_seg, n_utt * sizeof(double), hipMemcpyDeviceToHost, st));
-        AB_TRY(hipMemcpyAsync(seg_end, d_seg + n_utt, n_utt * sizeof(double), hipMemcpyDeviceToHost, st));
-        AB_TRY(hipMemcpyAsync(seg_score, d_seg + 2 * n_utt, n_utt * sizeof(double), hipMemcpyDeviceToHost, st));
-    }
+    // the staging block h is reused for the download: wait until the upload and the kernels are done
     AB_TRY(hipStreamSynchronize(st));
+    AB_TRY(hipMemcpy(h, d_out, out_bytes, hipMemcpyDeviceToHost));
+    std::memcpy(frame_of_label, h + o_fol, n_lab * 4);
+    std::memcpy(char_prob, h + o_cp, n_frm * 4);
+    if (state) std::memcpy(state, h + o_state, n_frm * 4);
+    std::memcpy(t_end, h + o_tend, (size_t)batch * 4);
+    std::memcpy(status, h + o_status, (size_t)batch * 4);
+    if (want_seg) {
+        std::memcpy(seg_start, h + o_seg, n_utt * 8);
+        std::memcpy(seg_end, h + o_seg + n_utt * 8, n_utt * 8);
+        std::memcpy(seg_score, h + o_seg + 2 * n_utt * 8, n_utt * 8);
+    }
 #undef AB_TRY
-#undef SCRATCH
-    cleanup();
+    ctcfa_plan_destroy(pl);
     return CTCFA_OK;
 }
 
