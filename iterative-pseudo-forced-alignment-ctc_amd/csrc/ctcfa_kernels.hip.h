@@ -868,43 +868,59 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             int b0 = 31 - ((t_end - 1) & 31);
             const uint32_t* seg_bits = bits + sd.bits_off;
             // Per 32-row block: lane i holds the decision word of column (pc - i) (the path can drop
-            // at most 32 columns inside the block).  The 32x64 bit tile is transposed with one
-            // ballot per row (bit i of row mask b = "column pc-i switches at row b"), after which
-            // the walk is straight-line scalar code: p += (mask_b >> p) & 1 -- three dependent
-            // SALU ops per row, no branch.  The next block's words are requested before this
-            // block is walked, so their HBM/L2 latency overlaps the scalar chain.
-            auto fetch = [&](int jb, int base) -> uint32_t {
-                const int col = base - lane;
+            // at most 32 columns inside the block).  The words of a block are requested kDepth
+            // blocks ahead, when its entry column is only known to lie within 32*kDepth columns
+            // below the current one: three loads cover columns [base-191, base], and the lane index
+            // is re-based with a shuffle once the block is reached.  (One block ahead was not
+            // enough: a block is walked in ~0.2 us, a miss in the decision words costs ~1 us.)
+            constexpr int kDepth = 4;
+            auto fetch = [&](int jb, int base, int part) -> uint32_t {
+                const int col = base - 64 * part - lane;
                 // columns at or left of the start column (<= shift) always STAY: their bits read as 0
                 return (jb >= 0 && col - shift > 0) ? seg_bits[(int64_t)jb * p.Cpad + col] : 0u;
             };
-            uint32_t wl = fetch(j, pc);
-            while (j >= 0) {
-                const int cstart = pc;
-                // speculative request for the next block, relative to the column we are at now; the
-                // true entry column of that block is <= 32 lower, so re-base the lane index below
-                const uint32_t wn = fetch(j - 1, cstart);
-                const uint32_t wn2 = fetch(j - 1, cstart - 32);
-                uint32_t S = 0;
-                int pidx = 0;  // columns dropped so far in this block
+            uint32_t pf[kDepth][3];
+            int pbase[kDepth];
 #pragma unroll
-                for (int bb = 0; bb < kRows; ++bb) {
-                    const unsigned long long rowmask = __builtin_amdgcn_ballot_w64(((wl >> bb) & 1u) != 0u);
-                    const uint32_t bit = (bb >= b0) ? (uint32_t)((rowmask >> pidx) & 1ull) : 0u;
-                    pidx += (int)bit;
-                    S |= bit << bb;
+            for (int u = 0; u < kDepth; ++u) {
+                pbase[u] = pc;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - u, pc, q);
+            }
+            while (j >= 0) {
+#pragma unroll
+                for (int u = 0; u < kDepth; ++u) {
+                    if (j < 0) break;
+                    const int cstart = pc;
+                    // this block's words for columns pc - lane, out of the loads issued for slot u
+                    const int src = (pbase[u] - pc) + lane;  // 0 .. 191
+                    const uint32_t f0 = __shfl(pf[u][0], src & 63);
+                    const uint32_t f1 = __shfl(pf[u][1], src & 63);
+                    const uint32_t f2 = __shfl(pf[u][2], src & 63);
+                    const uint32_t wl = (src < 64) ? f0 : (src < 128) ? f1 : f2;
+                    // slot u is free again: request block j - kDepth relative to the column we are at
+                    pbase[u] = pc;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - kDepth, pc, q);
+                    // Walk the block switch by switch, not row by row: the word of the current column
+                    // sits in lane pidx; its lowest set bit at or above the current row is the next
+                    // SWITCH (every row in between STAYs), then the column index drops by one.
+                    uint32_t S = 0;
+                    int pidx = 0;  // columns dropped so far in this block
+                    int bb = b0;
+                    while (bb < kRows) {
+                        const uint32_t wcur = (uint32_t)__builtin_amdgcn_readlane((int)wl, pidx) >> bb;
+                        if (wcur == 0u) break;             // stays until the block's first row
+                        bb += __builtin_ctz(wcur);
+                        S |= 1u << bb;
+                        ++pidx;
+                        ++bb;
+                    }
+                    pc -= pidx;
+                    if (lane == 0) rec[j] = make_int2(cstart, (int)S);
+                    --j;
+                    b0 = 0;
                 }
-                pc -= pidx;
-                if (lane == 0) rec[j] = make_int2(cstart, (int)S);
-                --j;
-                b0 = 0;
-                // next block's words for columns pc - i: lane i takes them from the two speculative
-                // loads (wn: columns cstart - i, wn2: columns cstart - 32 - i)
-                const int drop = cstart - pc;            // 0..32
-                const int src = lane + drop;             // lane of wn that holds column pc - lane
-                const uint32_t from_n = __shfl(wn, src & 63);
-                const uint32_t from_n2 = __shfl(wn2, (src - 32) & 63);
-                wl = (src < 64) ? from_n : from_n2;
             }
             if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
         } else {
