@@ -382,7 +382,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // later-dispatched waves would always lose and every step ends at a barrier that waits for
     // them.  Static priorities (younger half above older half, both above the light producer)
     // even the waves out: -4 % kernel time.
-    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
+    // In the mixed shape the heavy tiles are the critical ones (the light tiles wait for them at
+    // every barrier anyway): priority by weight there (-4 % again).
+    if (KH != KL ? (my.role == kRoleHeavy) : (w >= (W + 1) / 2)) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(1);
 
     // Dead zone: column c cannot reach the end cell's column C-1 from rows t > T-C+c, so the

@@ -71,6 +71,27 @@ def patch_P(k, h):
     return k, h
 
 
+def patch_Q1(k, h):
+    """wave priorities by tile weight: heavy tiles 2, light tiles 1"""
+    k = sub(k, "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone",
+            "    if (my.role == kRoleHeavy) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone")
+    return k, h
+
+
+def patch_Q2(k, h):
+    """all compute waves at priority 1"""
+    k = sub(k, "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone",
+            "    __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone")
+    return k, h
+
+
+def patch_Q3(k, h):
+    """older half above younger half (the reverse of the shipped order)"""
+    k = sub(k, "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone",
+            "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(1);\n    else __builtin_amdgcn_s_setprio(2);\n\n    // Dead zone")
+    return k, h
+
+
 def patch_stamp(k, h):
     stamp_def = """
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(seg_lastcol);
@@ -111,7 +132,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
