@@ -173,6 +173,13 @@ ctcfa::FillRoles mixed8_roles(int KH, int KL) {
     return r;
 }
 
+// Vocabularies staged row by row (32 < pitch <= 64, V != pitch): the eighth wave of the mixed
+// shape becomes a second producer, each stages every other row.
+void split_producer(ctcfa::FillRoles* r) {
+    r->wave[5] = {ctcfa::kRoleProducer, 0, 2};
+    r->wave[7] = {ctcfa::kRoleProducer, 1, 2};
+}
+
 const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
 
 int lds_bytes_fill(int W, int VP) {
@@ -420,6 +427,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->W = shape.W;
     pl->KL = shape.mixed ? shape.K / 2 : shape.K;
     pl->roles = shape.mixed ? mixed8_roles(pl->K, pl->KL) : uniform_roles(pl->K, pl->W);
+    if (shape.mixed && pl->VP > 32 && pl->VP <= 64 && vocab != pl->VP) split_producer(&pl->roles);
     if (gather) {  // W compute waves, no producer
         pl->roles.nwaves = pl->W;
         pl->roles.wave[pl->W] = {ctcfa::kRoleIdle, 0, 0};

@@ -150,13 +150,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const int nsteps = nblk + W - 1;
 
     for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = kProbMax;
+    if (tid == 0) *posflag = 0;  // producers raise it only after the first barrier, nobody reads it before the second
 
     if (my.role == kRoleIdle) {
         lds_barrier();  // its share of the ring initialisation is visible; from here on a
         return;         // finished wave no longer counts at s_barrier
     }
     if (my.role == kRoleProducer) {
-        if (lane == 0) *posflag = 0;  // same wave as every later write of the flag: ordered
         // ============================ producer wave ===========================================
         // Block jb = rows t in [32*jb + 1, 32*jb + 32].  One pass of the wave covers 64/VP rows
         // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
@@ -255,9 +255,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             float4 ea[NP], eb[NP];
             vload(0, ea);
             vwrite(0, ea);
-            publish_flag();
             if (1 < nblk) vload(1, ea);
             lds_barrier();
+            publish_flag();
             for (int s = 0; s < nsteps; s += 2) {
                 if (s + 2 < nblk) vload(s + 2, eb);
                 if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
@@ -277,53 +277,64 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int svl = lane < V ? lane : V - 1;             // lanes past the vocabulary re-read its last entry
             // LDS entry a lane writes: its own, the pseudo entry VP, or (lanes past VP) the pad entry VP+1
             const uint32_t ent = static_cast<uint32_t>((lane == kPseudoLane ? VP : (lane <= VP ? lane : VP + 1)) * 8);
-            auto rload = [&](int jb, float (&e)[kRows]) {
-                const int t0 = jb * kRows + 1;
+            // The role entry of a producer says which share of the rows it stages: part `stage` of
+            // `cbase` parts (the mixed shape makes its otherwise idle eighth wave a second producer,
+            // on the other lightly loaded SIMD).
+            const int part = my.stage;
+            auto run = [&](auto parts_tag) {
+                constexpr int PARTS = decltype(parts_tag)::value;
+                constexpr int NR = kRows / PARTS;  // rows of a block this wave stages: part, part + PARTS, ..
+                auto rload = [&](int jb, float (&e)[NR]) {
+                    const int t0 = jb * kRows + 1 + part;
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) {
-                    int t = t0 + r;
-                    t = t < T ? t : T - 1;
-                    e[r] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V) * 4u +
-                                                           static_cast<uint32_t>(svl) * 4u);
-                }
-            };
-            auto rwrite = [&](int jb, const float (&e)[kRows]) {
-                unsigned char* dst = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) + ent;
-                const int t0 = jb * kRows + 1;
+                    for (int i = 0; i < NR; ++i) {
+                        int t = t0 + i * PARTS;
+                        t = t < T ? t : T - 1;
+                        e[i] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V) * 4u +
+                                                               static_cast<uint32_t>(svl) * 4u);
+                    }
+                };
+                auto rwrite = [&](int jb, const float (&e)[NR]) {
+                    unsigned char* dst = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) + ent +
+                                         static_cast<uint32_t>(part * (PITCH * 8));
+                    const int t0 = jb * kRows + 1 + part;
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) {
-                    const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), blank));
-                    const bool valid = (t0 + r) < T;  // uniform
-                    notneg |= !(e[r] <= 0.0f);
-                    float2 v = make_float2(e[r], max3f(lb, e[r], kProbMax));
-                    if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                    if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
-                    *reinterpret_cast<float2*>(dst + r * (PITCH * 8)) = v;
-                }
-            };
-            // One register set: the loads of block s+2 are issued right after block s+1 has been
-            // written and have a whole step (~3 us) to arrive.  (A second set would cost 32 VGPRs
-            // of every wave of the kernel, i.e. the room the overlapped backtrack kernel lives in.)
-            float ea[kRows];
-            rload(0, ea);
-            rwrite(0, ea);
-            publish_flag();
-            if (1 < nblk) rload(1, ea);
-            lds_barrier();
-            for (int s = 0; s < nsteps; ++s) {
-                if (s + 1 < nblk) { rwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
-                if (s + 2 < nblk) rload(s + 2, ea);
+                    for (int i = 0; i < NR; ++i) {
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), blank));
+                        const bool valid = (t0 + i * PARTS) < T;  // uniform
+                        notneg |= !(e[i] <= 0.0f);
+                        float2 v = make_float2(e[i], max3f(lb, e[i], kProbMax));
+                        if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                        if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
+                    }
+                };
+                // One register set: the loads of block s+2 are issued right after block s+1 has been
+                // written and have a whole step (~3 us) to arrive.  (A second set would cost 32 VGPRs
+                // of every wave of the kernel, i.e. the room the overlapped backtrack kernel lives in.)
+                float ea[NR];
+                rload(0, ea);
+                rwrite(0, ea);
+                if (1 < nblk) rload(1, ea);
                 lds_barrier();
-            }
+                publish_flag();
+                for (int s = 0; s < nsteps; ++s) {
+                    if (s + 1 < nblk) { rwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
+                    if (s + 2 < nblk) rload(s + 2, ea);
+                    lds_barrier();
+                }
+            };
+            if (my.cbase == 2) run(std::integral_constant<int, 2>{});
+            else run(std::integral_constant<int, 1>{});
         } else if constexpr (PASSES == CH) {
 
             // whole block in one chunk (VP == 32): two register sets, swapped by 2x unrolling
             float ea[CH], eb[CH];
             load_chunk(0, 0, ea);
             write_chunk(0, 0, ea);
-            publish_flag();
             if (1 < nblk) load_chunk(1, 0, ea);
             lds_barrier();
+            publish_flag();
             for (int s = 0; s < nsteps; s += 2) {
                 if (s + 2 < nblk) load_chunk(s + 2, 0, eb);
                 if (s + 1 < nblk) { write_chunk(s + 1, 0, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
@@ -342,12 +353,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     load_chunk(jb, p0, e);
                     write_chunk(jb, p0, e);
                 }
-                publish_flag();
             };
             stage_block(0);
             lds_barrier();
+            publish_flag();
             for (int s = 0; s < nsteps; ++s) {
-                if (s + 1 < nblk) stage_block(s + 1);
+                if (s + 1 < nblk) { stage_block(s + 1); publish_flag(); }
                 lds_barrier();
             }
         }

@@ -71,25 +71,22 @@ def patch_P(k, h):
     return k, h
 
 
+PRIO_ANCHOR = "    if (KH != KL ? (my.role == kRoleHeavy) : (w >= (W + 1) / 2)) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);"
+
+
 def patch_Q1(k, h):
-    """wave priorities by tile weight: heavy tiles 2, light tiles 1"""
-    k = sub(k, "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone",
-            "    if (my.role == kRoleHeavy) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone")
-    return k, h
+    """heavy 3, light 1"""
+    return sub(k, PRIO_ANCHOR, "    __builtin_amdgcn_s_setprio(my.role == kRoleHeavy ? 3 : 1);"), h
 
 
 def patch_Q2(k, h):
-    """all compute waves at priority 1"""
-    k = sub(k, "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone",
-            "    __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone")
-    return k, h
+    """heavy 2, light 0 (with the producer)"""
+    return sub(k, PRIO_ANCHOR, "    __builtin_amdgcn_s_setprio(my.role == kRoleHeavy ? 2 : 0);"), h
 
 
 def patch_Q3(k, h):
-    """older half above younger half (the reverse of the shipped order)"""
-    k = sub(k, "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);\n\n    // Dead zone",
-            "    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(1);\n    else __builtin_amdgcn_s_setprio(2);\n\n    // Dead zone")
-    return k, h
+    """heavy: later stages above earlier ones (3/2), light 1"""
+    return sub(k, PRIO_ANCHOR, "    __builtin_amdgcn_s_setprio(my.role == kRoleHeavy ? (w >= 2 ? 3 : 2) : 1);"), h
 
 
 def patch_stamp(k, h):
