@@ -173,6 +173,21 @@ ctcfa::FillRoles mixed8_roles(int KH, int KL) {
     return r;
 }
 
+// Six equal tiles on 8 waves: pairs (H,H), (H,producer), (H,H), (H,idle) -> with the neighbour
+// workgroup rotated by one SIMD every SIMD of the CU carries exactly 3 tiles (a 7-wave workgroup
+// leaves one SIMD with 4).
+ctcfa::FillRoles balanced8_roles(int K) {
+    ctcfa::FillRoles r{};
+    r.nwaves = 8;
+    r.nstages = 6;
+    r.cpad = 64 * K * 6;
+    const int tile_wave[6] = {0, 2, 4, 6, 1, 3};
+    for (int i = 0; i < 6; ++i) r.wave[tile_wave[i]] = {ctcfa::kRoleHeavy, (int8_t)i, (int16_t)(i * 64 * K)};
+    r.wave[5] = {ctcfa::kRoleProducer, 0, 0};
+    r.wave[7] = {ctcfa::kRoleIdle, 0, 0};
+    return r;
+}
+
 // Vocabularies staged row by row (32 < pitch <= 64, V != pitch): the eighth wave of the mixed
 // shape becomes a second producer, each stages every other row.
 void split_producer(ctcfa::FillRoles* r) {
@@ -198,7 +213,7 @@ int roundup(int x, int m) { return (x + m - 1) / m * m; }
 //   G workgroups share a CU (LDS, wave slots, VGPRs); a batch takes ceil(B / (G x CUs)) rounds.
 // `mixed` reports whether the 8-wave shape (4 heavy + 2 light tiles, 2 heavy + 1 light per SIMD)
 // beats five equal tiles.
-struct ShapeChoice { int K, W; bool mixed; };
+struct ShapeChoice { int K, W; bool mixed; bool balanced8 = false; };
 
 int vgprs_of(int K) {  // compiled register counts, rounded up (allocation granule 8)
     switch (K) {
@@ -245,7 +260,7 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
         const double cost = rounds * std::max(wave_bound, simd_bound) * (1.0 + 1e-3 * pad) + 1e-3 * waves_per_wg;
         if (best_cost < 0.0 || cost < best_cost) {
             best_cost = cost;
-            best = {K, W, mixed};
+            best = {K, W, mixed, !mixed && W == 6 && waves_per_wg == 8};
         }
     };
     for (int K : kKs) {
@@ -255,6 +270,7 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
         if (W > 15 || (K >= 10 && W > 4)) continue;  // +1 producer wave; K >= 10 kernels: <= 320 threads
         consider(K, W, false, W, W + 1);
         if (!force_k && allow_mixed && W == 5 && (K == 2 || K == 4)) consider(K, W, true, 6, 8);
+        if (!force_k && allow_mixed && W == 6) consider(K, W, false, 6, 8);  // six equal tiles on 8 waves
     }
     if (!best.K) return false;
     *out = best;
@@ -426,7 +442,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->K = shape.K;
     pl->W = shape.W;
     pl->KL = shape.mixed ? shape.K / 2 : shape.K;
-    pl->roles = shape.mixed ? mixed8_roles(pl->K, pl->KL) : uniform_roles(pl->K, pl->W);
+    pl->roles = shape.mixed ? mixed8_roles(pl->K, pl->KL)
+                            : (shape.balanced8 ? balanced8_roles(pl->K) : uniform_roles(pl->K, pl->W));
     if (shape.mixed && pl->VP > 32 && pl->VP <= 64 && vocab != pl->VP) split_producer(&pl->roles);
     if (gather) {  // W compute waves, no producer
         pl->roles.nwaves = pl->W;
