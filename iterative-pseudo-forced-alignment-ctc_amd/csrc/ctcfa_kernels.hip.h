@@ -921,13 +921,30 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
                     uint32_t S = 0;
                     int pidx = 0;  // columns dropped so far in this block
                     int bb = b0;
-                    while (bb < kRows) {
-                        const uint32_t wcur = (uint32_t)__builtin_amdgcn_readlane((int)wl, pidx) >> bb;
-                        if (wcur == 0u) break;             // stays until the block's first row
-                        bb += __builtin_ctz(wcur);
-                        S |= 1u << bb;
-                        ++pidx;
-                        ++bb;
+                    // (hand-scheduled: the compiler's version of this loop spends 16 scalar
+                    // instructions and four branches per switch)
+                    //   while (bb < 32) { w = readlane(wl, pidx) >> bb; if (!w) break;
+                    //                     bb += ctz(w); S |= 1 << bb; ++pidx; ++bb; }
+                    if (bb < kRows) {
+                        uint32_t tmp;
+                        asm volatile(
+                            "1:\n\t"
+                            "s_nop 3\n\t"                        // lane select written by the previous SALU op
+                            "v_readlane_b32 %3, %4, %1\n\t"
+                            "s_lshr_b32 %3, %3, %2\n\t"
+                            "s_cmp_eq_u32 %3, 0\n\t"
+                            "s_cbranch_scc1 2f\n\t"
+                            "s_ff1_i32_b32 %3, %3\n\t"
+                            "s_add_i32 %3, %3, %2\n\t"
+                            "s_bitset1_b32 %0, %3\n\t"
+                            "s_add_i32 %2, %3, 1\n\t"
+                            "s_add_i32 %1, %1, 1\n\t"
+                            "s_cmp_lt_i32 %2, 32\n\t"
+                            "s_cbranch_scc1 1b\n\t"
+                            "2:"
+                            : "+s"(S), "+s"(pidx), "+s"(bb), "=&s"(tmp)
+                            : "v"(wl)
+                            : "scc");
                     }
                     pc -= pidx;
                     if (lane == 0) rec[j] = make_int2(cstart, (int)S);
