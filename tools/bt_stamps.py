@@ -23,3 +23,5 @@ torch.cuda.synchronize()
 p0, pa = st.cpu().numpy(), te.cpu().numpy()
 pb, pc = seg[0].cpu().numpy().reshape(B, U)[:, 0], seg[1].cpu().numpy().reshape(B, U)[:, 0]
 print("backtrack phases, median cycles per segment: argmax %d | walk %d | per-frame %d | scoring %d" % (np.median(p0), np.median(pa), np.median(pb), np.median(pc)))
+sw = seg[2].cpu().numpy().reshape(B, U)[:, 0]
+print("  of the walk, inside the switch loop (btwalk variant only): %d; t_end median %d" % (np.median(sw), 0))

@@ -71,6 +71,17 @@ def patch_P(k, h):
     return k, h
 
 
+def patch_btwalk(k, h):
+    """btstamp + split of the walk: cycles inside the switch loop go to seg_score[first utt]"""
+    k, h = patch_btstamp(k, h)
+    k = sub(k, "                    if (bb < kRows) {\n                        uint32_t tmp;", "                    const unsigned long long sw0 = __builtin_amdgcn_s_memtime();\n                    if (bb < kRows) {\n                        uint32_t tmp;")
+    k = sub(k, "                    pc -= pidx;\n                    if (lane == 0) rec[j] = make_int2(cstart, (int)S);", "                    sw_acc += __builtin_amdgcn_s_memtime() - sw0;\n                    pc -= pidx;\n                    if (lane == 0) rec[j] = make_int2(cstart, (int)S);")
+    k = sub(k, "            constexpr int kDepth = 4;", "            unsigned long long sw_acc = 0;\n            constexpr int kDepth = 4;")
+    k = sub(k, "            if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError", "            if (lane == 0 && seg_score) seg_score[sd.utt_off] = (double)sw_acc;\n            if (pc - shift > 0) bad = 1;")
+    k = sub(k, "            seg_score[sd.utt_off + u] = min_avg;", "            if (u > 0) seg_score[sd.utt_off + u] = min_avg;")
+    return k, h
+
+
 PRIO_ANCHOR = "    if (KH != KL ? (my.role == kRoleHeavy) : (w >= (W + 1) / 2)) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(1);"
 
 
@@ -125,11 +136,12 @@ def patch_btstamp(k, h):
     k = sub(k, "    // ---- phase A (wave 0): the walk", "    const unsigned long long bt1 = __builtin_amdgcn_s_memtime();\n    // ---- phase A (wave 0): the walk")
     k = sub(k, "    // ---- phase B: per-frame outputs, lanes = frames", "    const unsigned long long bt2 = __builtin_amdgcn_s_memtime();\n    // ---- phase B: per-frame outputs, lanes = frames")
     k = sub(k, "    if (!want_seg) return;\n    __threadfence_block();", "    const unsigned long long bt3 = __builtin_amdgcn_s_memtime();\n    if (!want_seg) return;\n    __threadfence_block();")
-    k = sub(k, "            seg_score[sd.utt_off + u] = min_avg;\n        }\n    }\n}", "            seg_score[sd.utt_off + u] = min_avg;\n        }\n    }\n    __syncthreads();\n    const unsigned long long bt4 = __builtin_amdgcn_s_memtime();\n    if (tid == 0) { status_out[sd.seg_index] = (int)(bt1 - bt0); t_end_out[sd.seg_index] = (int)(bt2 - bt1); seg_start[sd.utt_off] = (double)(bt3 - bt2); seg_end[sd.utt_off] = (double)(bt4 - bt3); }\n}")
+    k = sub(k, "    score_utterances<kBtThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,\n                                 seg_start, seg_end, seg_score);\n}",
+            "    score_utterances<kBtThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,\n                                 seg_start, seg_end, seg_score);\n    __syncthreads();\n    const unsigned long long bt4 = __builtin_amdgcn_s_memtime();\n    if (tid == 0) { status_out[sd.seg_index] = (int)(bt1 - bt0); t_end_out[sd.seg_index] = (int)(bt2 - bt1); seg_start[sd.utt_off] = (double)(bt3 - bt2); seg_end[sd.utt_off] = (double)(bt4 - bt3); }\n}")
     return k, h
 
 
-PATCHES = {"Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"btwalk": patch_btwalk, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
