@@ -929,7 +929,9 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
                         uint32_t tmp;
                         asm volatile(
                             "1:\n\t"
-                            "s_nop 3\n\t"                        // lane select written by the previous SALU op
+                            "s_nop 3\n\t"                        // wl was just written by a VALU op: gfx940 needs a wait
+                                                                 // state before v_readlane reads it (and the
+                                                                 // hazard recogniser does not look inside asm)
                             "v_readlane_b32 %3, %4, %1\n\t"
                             "s_lshr_b32 %3, %3, %2\n\t"
                             "s_cmp_eq_u32 %3, 0\n\t"
