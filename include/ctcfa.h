@@ -141,9 +141,12 @@ int ctcfa_plan_flush(ctcfa_plan* plan, void* stream);
 
 /* Kernel timing with HIP events recorded on the stream the kernels run on.
  * set_timing(slots): keep the events of the last `slots` runs (0 = off, the default).
- * get_timings(n, ...): durations [ms] of the last n runs, oldest first; synchronises
+ * set_timing_stride(k): record only every k-th run (an event record is a queue packet between
+ * two kernels; k > 1 samples the run durations at a fraction of that cost).  Default 1.
+ * get_timings(n, ...): durations [ms] of the last n RECORDED runs, oldest first; synchronises
  * on those runs' end events.  fill_ms / backtrack_ms: float[n], either may be NULL. */
 int ctcfa_plan_set_timing(ctcfa_plan* plan, int slots);
+int ctcfa_plan_set_timing_stride(ctcfa_plan* plan, int stride);
 int ctcfa_plan_get_timings(ctcfa_plan* plan, int n, float* fill_ms, float* backtrack_ms);
 
 /*

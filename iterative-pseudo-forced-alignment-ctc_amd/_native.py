@@ -25,7 +25,7 @@ EXPORTS = (
     "ctcfa_last_error", "ctcfa_default_params", "ctcfa_plan_create", "ctcfa_plan_destroy",
     "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_run_pipelined", "ctcfa_plan_flush",
     "ctcfa_plan_get_timings",
-    "ctcfa_plan_set_timing", "ctcfa_align_batch",
+    "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch",
 )
 
 
@@ -98,6 +98,7 @@ def load():
     lib.ctcfa_plan_get_timings.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]
     lib.ctcfa_plan_set_timing.argtypes = [vp, ctypes.c_int]
+    lib.ctcfa_plan_set_timing_stride.argtypes = [vp, ctypes.c_int]
     lib.ctcfa_align_batch.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
                                       i32p, i32p, i32p] + [vp] * 11
     _lib = lib
@@ -234,6 +235,10 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def set_timing_stride(self, stride):
+        """Record timing events only on every ``stride``-th run."""
+        self._eng._check(self._lib.ctcfa_plan_set_timing_stride(self._h, int(stride)), "ctcfa_plan_set_timing_stride")
 
     def set_timing(self, slots):
         """Keep HIP-event timings of the last ``slots`` runs (0 switches recording off)."""

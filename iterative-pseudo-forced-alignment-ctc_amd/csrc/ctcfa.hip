@@ -61,6 +61,8 @@ struct ctcfa_plan {
     std::vector<hipEvent_t> ev;
     int ev_slots = 0;
     int64_t ev_runs = 0;
+    int ev_stride = 1;       // record timing events on every ev_stride-th run
+    int64_t run_counter = 0;
     void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
                     const ctcfa::FillRoles*) = nullptr;
     // windowed regime (T > min_window_size): segment indices, fp32 table + per-column offsets
@@ -619,6 +621,13 @@ int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
     return CTCFA_OK;
 }
 
+int ctcfa_plan_set_timing_stride(ctcfa_plan* pl, int stride) {
+    if (!pl || stride < 1) return CTCFA_ERR_INVALID;
+    pl->ev_stride = stride;
+    pl->run_counter = 0;
+    return CTCFA_OK;
+}
+
 int ctcfa_plan_set_timing(ctcfa_plan* pl, int slots) {
     if (!pl || slots < 0 || slots > 4096) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
@@ -727,7 +736,8 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
         HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[0], 0));
         pl->bt_pending[0] = false;
     }
-    hipEvent_t* ev = pl->ev_slots ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
+    const bool timed = pl->ev_slots && (pl->run_counter++ % pl->ev_stride == 0);
+    hipEvent_t* ev = timed ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
     if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
     if ((rc = launch_fill(pl, a, 0, st)) != CTCFA_OK) return rc;
     if (ev) {
@@ -766,11 +776,15 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     }
     const int q = (int)(pl->pipe_runs & 1);
     // workspace q was last read by the backtrack of run k-2
-    if (pl->bt_pending[q]) HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
+    // (asked on the host first: the backtrack of run k-2 is normally long done, and a wait that is
+    // already satisfied still costs the queue a packet between two fill kernels)
+    if (pl->bt_pending[q] && hipEventQuery(pl->bt_done_ev[q]) != hipSuccess)
+        HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
     // With timing on, the "end" timing events double as the hand-over events: every event record
     // is a packet the queue has to retire between two kernels.  (The ring has >= 4 slots, so the
     // event of run k is still untouched when run k+2 waits on it.)
-    hipEvent_t* ev = pl->ev_slots >= 4 ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
+    const bool timed = pl->ev_slots >= 4 && (pl->run_counter++ % pl->ev_stride == 0);
+    hipEvent_t* ev = timed ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
     if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
     if ((rc = launch_fill(pl, a, q, st)) != CTCFA_OK) return rc;
     hipEvent_t fill_done = ev ? ev[1] : pl->ev_fill_done[q];
