@@ -692,10 +692,10 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.L = pl->prm.score_min_mean_over_L;
     bp.rec_bytes = pl->rec_bytes;
     bp.dur = pl->prm.index_duration;
-    hipLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st, pl->d_segs,
-                       a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws], pl->d_lastcol[ws],
-                       bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
-                       want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status);
+    const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
+                           pl->d_lastcol[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
+                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
+    hipLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st, ba);
     HIP_TRY(pl->eng, hipGetLastError());
     if (!pl->win_list.empty()) {
         ctcfa::WinParams wp;

@@ -723,13 +723,18 @@ __device__ __forceinline__ double np_pairwise_sum_le128(const float* a, int n) {
 // determine_utterance_segments() of ctc-segmentation 1.7.1 for one segment: utterances over
 // waves, lanes = sliding windows.  `fol` = frame of every label column (read with agent-scope
 // loads: written by other waves of this workgroup), `cps` = the segment's char_probs in LDS.
-template <int NTHREADS>
+struct NoTick {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+template <int NTHREADS, class Tick = NoTick>
 __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, double dur, const int32_t* ub,
                                                  const int32_t* fol, const float* cps, int T, int C, int U,
                                                  double* __restrict__ seg_start, double* __restrict__ seg_end,
-                                                 double* __restrict__ seg_score) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                                                 double* __restrict__ seg_score, int tid = -1, Tick tick = Tick()) {
+    if (tid < 0) tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = NTHREADS / 64;
     auto tim = [&](int c) {
         if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
@@ -756,7 +761,9 @@ __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, doubl
             min_avg = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
         } else {
             double local = 0.0;
+            int it = 0;
             for (long long t0 = start_t + lane; t0 < end_t - n; t0 += 64) {
+                if ((++it & 1) == 0) tick();
                 long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
                 if (lo > T) lo = T;
                 if (hi < lo) hi = lo;
@@ -775,28 +782,56 @@ __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, doubl
             seg_end[sd.utt_off + u] = end;
             seg_score[sd.utt_off + u] = min_avg;
         }
+        tick();
     }
 }
 
-__global__ void __launch_bounds__(kBtThreads)
-backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
-                 const int32_t* __restrict__ labels, const int32_t* __restrict__ utt_begin,
-                 const uint32_t* __restrict__ bits, const float* __restrict__ lastcol,
-                 BtParams p, int32_t* __restrict__ frame_of_label, float* __restrict__ char_prob,
-                 int32_t* __restrict__ state, double* __restrict__ seg_start,
-                 double* __restrict__ seg_end, double* __restrict__ seg_score,
-                 int32_t* __restrict__ t_end_out, int32_t* __restrict__ status_out) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ float red_v[kBtThreads / 64];
-    __shared__ int red_t[kBtThreads / 64];
-    __shared__ int sh_misc[2];  // [0] t_end, [1] bad
+// Everything the backtrack needs, as one argument: the stand-alone kernel below and the backtrack
+// wave fused into the mixed-shape fill kernel run the same body.
+struct BtArgs {
+    const SegDesc* segs;
+    const float* lpz;
+    const int32_t* labels;
+    const int32_t* utt_begin;
+    const uint32_t* bits;
+    const float* lastcol;
+    BtParams p;
+    int32_t* frame_of_label;
+    float* char_prob;
+    int32_t* state;
+    double* seg_start;
+    double* seg_end;
+    double* seg_score;
+    int32_t* t_end_out;
+    int32_t* status_out;
+};
+
+// NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
+// `sync` separates the phases, `tick` is called between slices of work (the fused wave has to
+// take part in the fill workgroup's barriers while it lives).
+template <int NT, class Sync, class Tick>
+__device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& sd, int tid, unsigned char* smem,
+                                               float* red_v, int* red_t, int* sh_misc, Sync sync, Tick tick) {
+    const BtParams& p = a.p;
+    const float* __restrict__ lpz = a.lpz;
+    const int32_t* __restrict__ labels = a.labels;
+    const int32_t* __restrict__ utt_begin = a.utt_begin;
+    const uint32_t* __restrict__ bits = a.bits;
+    const float* __restrict__ lastcol = a.lastcol;
+    int32_t* __restrict__ frame_of_label = a.frame_of_label;
+    float* __restrict__ char_prob = a.char_prob;
+    int32_t* __restrict__ state = a.state;
+    double* __restrict__ seg_start = a.seg_start;
+    double* __restrict__ seg_end = a.seg_end;
+    double* __restrict__ seg_score = a.seg_score;
+    int32_t* __restrict__ t_end_out = a.t_end_out;
+    int32_t* __restrict__ status_out = a.status_out;
+    constexpr int kThreads = NT;
     int2* rec = reinterpret_cast<int2*>(smem);                   // per block: (entry column, switch mask)
     float* cps = reinterpret_cast<float*>(smem + p.rec_bytes);   // char_probs of this segment
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = kBtThreads / 64;
-    const SegDesc sd = segs[blockIdx.x];
+    constexpr int NW = kThreads / 64;
     const int T = sd.T, C = sd.C, U = sd.U, shift = sd.shift, V = p.V;
     const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
@@ -806,13 +841,13 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
     const bool want_seg = (utt_begin != nullptr) && (seg_score != nullptr) && U > 0;
 
     auto fail = [&](int code) {
-        for (int c = tid; c < C; c += kBtThreads) fol[c] = 0;
-        for (int t = tid; t < T; t += kBtThreads) {
+        for (int c = tid; c < C; c += kThreads) fol[c] = 0;
+        for (int t = tid; t < T; t += kThreads) {
             cp[t] = 0.0f;
             if (st) st[t] = -2;
         }
         if (want_seg)
-            for (int u = tid; u < U; u += kBtThreads) {
+            for (int u = tid; u < U; u += kThreads) {
                 seg_start[sd.utt_off + u] = 0.0;
                 seg_end[sd.utt_off + u] = 0.0;
                 seg_score[sd.utt_off + u] = 0.0;
@@ -833,7 +868,9 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
         const float* lc = lastcol + sd.frm_off;
         float bv = -__builtin_inff();
         int bt = 0x7fffffff;
-        for (int t = tid; t < T; t += kBtThreads) {
+        int it0 = 0;
+        for (int t = tid; t < T; t += kThreads) {
+            if ((++it0 & 7) == 0) tick();
             const float v = (t == 0) ? kProbMax : lc[t];  // table[0, C-1] = -1e9
             if (bt == 0x7fffffff || v > bv) {             // ascending t per thread: strict '>' keeps the first
                 bv = v;
@@ -855,9 +892,9 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
         }
     }
     const int nblk = (T - 1 + kRows - 1) / kRows;
-    for (int j = tid; j < nblk; j += kBtThreads) rec[j] = make_int2(-1, 0);
-    for (int c = tid; c < C; c += kBtThreads) fol[c] = 0;
-    __syncthreads();
+    for (int j = tid; j < nblk; j += kThreads) rec[j] = make_int2(-1, 0);
+    for (int c = tid; c < C; c += kThreads) fol[c] = 0;
+    sync();
 
     // ---- phase A (wave 0): the walk, one scalar step per run of STAYs ----------------------
     if (wave == 0) {
@@ -952,6 +989,7 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
                     if (lane == 0) rec[j] = make_int2(cstart, (int)S);
                     --j;
                     b0 = 0;
+                    if (u & 1) tick();
                 }
             }
             if (pc - shift > 0) bad = 1;  // reached t == 0 in a label column: the package's IndexError
@@ -963,7 +1001,7 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
             sh_misc[1] = bad;
         }
     }
-    __syncthreads();
+    sync();
     const int t_end = sh_misc[0];
     if (sh_misc[1]) {
         fail(2);
@@ -971,7 +1009,9 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
     }
 
     // ---- phase B: per-frame outputs, lanes = frames ---------------------------------------
-    for (int t = tid; t < T; t += kBtThreads) {
+    int itb = 0;
+    for (int t = tid; t < T; t += kThreads) {
+        if ((++itb & 3) == 0) tick();
         float prob = 0.0f;
         int s_lab = -2;
         if (t >= 1 && t <= t_end) {
@@ -1009,12 +1049,34 @@ backtrack_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz
         t_end_out[sd.seg_index] = t_end;
     }
     if (!want_seg) return;
-    __threadfence_block();
-    __syncthreads();
+    sync();
 
     // ---- phase C: determine_utterance_segments ------------------------------------------------
-    score_utterances<kBtThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,
-                                 seg_start, seg_end, seg_score);
+    score_utterances<kThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,
+                               seg_start, seg_end, seg_score, tid, tick);
+}
+
+struct BlockSync {
+    __device__ __forceinline__ void operator()() const {
+        __threadfence_block();
+        __syncthreads();
+    }
+};
+struct WaveSync {  // one wave: program order + completed memory operations is all a phase change needs
+    __device__ __forceinline__ void operator()() const {
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+__global__ void __launch_bounds__(kBtThreads)
+backtrack_kernel(BtArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float red_v[kBtThreads / 64];
+    __shared__ int red_t[kBtThreads / 64];
+    __shared__ int sh_misc[2];  // [0] t_end, [1] bad
+    const SegDesc sd = a.segs[blockIdx.x];
+    backtrack_body<kBtThreads>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
 }
 
 
