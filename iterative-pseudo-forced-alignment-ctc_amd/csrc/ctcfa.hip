@@ -733,7 +733,7 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     // a pipelined run may still be reading workspace 0 on the side stream
     if (pl->bt_pending[0]) {
-        HIP_TRY(eng, hipStreamWaitEvent(st, pl->ev_bt_done[0], 0));
+        HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[0], 0));
         pl->bt_pending[0] = false;
     }
     const bool timed = pl->ev_slots && (pl->run_counter++ % pl->ev_stride == 0);

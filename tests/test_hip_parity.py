@@ -691,3 +691,41 @@ def test_wide_vocabulary_long_label_sequences(pkg, oracle):
     _check(pkg, oracle, segs[1:], _run(pkg, segs[1:], **kw), cfg_kw=kw)
     with pytest.raises(NotImplementedError):
         _run(pkg, segs, preamble_transition_cost_zero=False)
+
+
+def test_serial_call_after_pipelined_calls_waits_for_the_pending_backtrack(pkg, engine):
+    """run_device right after run_pipelined (no flush in between) reuses workspace 0: it has to
+    wait for the side-stream backtrack that may still be reading it, also when kernel timing is
+    on and the hand-over events are the timing events."""
+    import torch
+    syn = pkg.synthetic
+    segs = [syn.make_segment(700 + s, 1500, 32, 12, 26) for s in range(64)]
+    T = [s[0].shape[0] for s in segs]
+    C = [len(s[1]) for s in segs]
+    U = [len(s[2]) - 1 for s in segs]
+    plan = engine.plan(pkg.CtcSegmentationParameters(index_duration=DUR).to_native(), 32, T, C, U)
+    plan.set_timing(8)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in segs])).to(dev)
+    d_lab = torch.from_numpy(np.concatenate([s[1] for s in segs]).astype(np.int32)).to(dev)
+    d_ub = torch.from_numpy(np.concatenate([s[2] for s in segs]).astype(np.int32)).to(dev)
+
+    def run(pipelined):
+        o = dict(fol=torch.zeros(sum(C), dtype=torch.int32, device=dev), cp=torch.zeros(sum(T), dtype=torch.float32, device=dev),
+                 seg=torch.zeros(3, sum(U), dtype=torch.float64, device=dev), te=torch.zeros(64, dtype=torch.int32, device=dev),
+                 status=torch.full((64,), -7, dtype=torch.int32, device=dev))
+        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(), o["cp"].data_ptr(), None,
+                        o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(), o["te"].data_ptr(),
+                        o["status"].data_ptr(), stream, pipelined=pipelined)
+        return o
+
+    ref = run(False)
+    torch.cuda.synchronize()
+    outs = [run(True), run(False), run(True), run(True), run(False)]
+    plan.flush(stream)
+    torch.cuda.synchronize()
+    for o in outs:
+        for k in ("status", "te", "fol", "seg"):
+            assert torch.equal(o[k], ref[k]), k
+    plan.close()
