@@ -29,9 +29,10 @@ def sub(s, old, new, count=1):
 
 
 def patch_A(k, h):
-    k = sub(k, "*reinterpret_cast<float*>(smem + out_addr + i * 4) = prev[K - 1];", "")
-    k = sub(k, "linq[d] = *reinterpret_cast<const float*>(smem + in_addr + d * 4);", "linq[d] = kProbMax;")
-    k = sub(k, "linq[i % PF] = *reinterpret_cast<const float*>(smem + in_addr + (i + PF) * 4);", "")
+    k = sub(k, "                    *reinterpret_cast<float4*>(smem + out_addr + (i - 2) * 4) = pub4;", "", count=1)
+    k = sub(k, "            float4 lin4 = *reinterpret_cast<const float4*>(smem + in_addr);",
+            "            float4 lin4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);", count=1)
+    k = sub(k, "                    if (i + 4 < kRows) lin4_next = *reinterpret_cast<const float4*>(smem + in_addr + (i + 4) * 4);", "", count=1)
     return k, h
 
 
@@ -87,44 +88,45 @@ PRIO_ANCHOR = "    if (KH != KL ? (my.role == kRoleHeavy) : (w >= (W + 1) / 2)) 
 
 def patch_Q1(k, h):
     """heavy 3, light 1"""
-    return sub(k, PRIO_ANCHOR, "    __builtin_amdgcn_s_setprio(my.role == kRoleHeavy ? 3 : 1);"), h
+    return sub(k, PRIO_ANCHOR, "    if (my.role == kRoleHeavy) __builtin_amdgcn_s_setprio(3);\n    else __builtin_amdgcn_s_setprio(1);"), h
 
 
 def patch_Q2(k, h):
     """heavy 2, light 0 (with the producer)"""
-    return sub(k, PRIO_ANCHOR, "    __builtin_amdgcn_s_setprio(my.role == kRoleHeavy ? 2 : 0);"), h
+    return sub(k, PRIO_ANCHOR, "    if (my.role == kRoleHeavy) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(0);"), h
 
 
 def patch_Q3(k, h):
     """heavy: later stages above earlier ones (3/2), light 1"""
-    return sub(k, PRIO_ANCHOR, "    __builtin_amdgcn_s_setprio(my.role == kRoleHeavy ? (w >= 2 ? 3 : 2) : 1);"), h
+    return sub(k, PRIO_ANCHOR, "    if (my.role != kRoleHeavy) __builtin_amdgcn_s_setprio(1);\n    else if (w >= 2) __builtin_amdgcn_s_setprio(3);\n    else __builtin_amdgcn_s_setprio(2);"), h
 
 
 def patch_stamp(k, h):
+    """s_memtime stamps of steps 40..55, slot (wave id, step, point): 0 = step start, 1 = before the
+    barrier, 2 = after it.  Unreachable/dead-zone skipping is compiled out so that every wave works
+    in every stamped step."""
     stamp_def = """
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(seg_lastcol);
     auto stamp = [&](int s_, int q_) {
         unsigned long long t_;
         asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        const int slot_ = (w * 16 + (s_ - 40)) * 3 + q_;
+        const int slot_ = (wave_id * 16 + (s_ - 40)) * 3 + q_;
         if (lane == 0 && blockIdx.x < 8 && s_ >= 40 && s_ < 56) stamps[slot_] = t_;
     };
 """
-    # define before the role split so that the producer can stamp too
-    k = sub(k, "    if (w == W) {\n        // ============================ producer wave", stamp_def + "    if (w == W) {\n        // ============================ producer wave")
-    k = sub(k, "        const int j = s - w;\n        if (j >= 0 && j < nblk) {\n            const int slot = j % NS;",
-            "        stamp(s, 0);\n        const int j = s - w;\n        if (j >= 0 && j < nblk) {\n            const int slot = j % NS;")
+    k = sub(k, "    if (my.role == kRoleProducer) {\n", stamp_def + "    if (my.role == kRoleProducer) {\n")
+    k = sub(k, "        const int j = s - w;\n        if (j >= 0 && j < jfirst) {", "        stamp(s, 0);\n        const int j = s - w;\n        if (j >= 0 && j < jfirst) {")
     k = sub(k, "        lds_barrier();\n    }\n    // row 32*nblk", "        stamp(s, 1);\n        lds_barrier();\n        stamp(s, 2);\n    }\n    // row 32*nblk")
-    # producer (vectorised path): stamp around its work
-    k = sub(k, "                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) vwrite(s + 1, ea);  // slot (s+1) % NS was last read in step s-1\n                lds_barrier();",
-            "                stamp(s, 0);\n                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) vwrite(s + 1, ea);\n                stamp(s, 1);\n                lds_barrier();\n                stamp(s, 2);")
-    k = sub(k, "                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                lds_barrier();",
-            "                stamp(s + 1, 0);\n                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) vwrite(s + 2, eb);\n                stamp(s + 1, 1);\n                lds_barrier();\n                stamp(s + 1, 2);")
+    k = sub(k, "                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1\n                lds_barrier();",
+            "                stamp(s, 0);\n                if (s + 2 < nblk) vload(s + 2, eb);\n                if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }\n                stamp(s, 1);\n                lds_barrier();\n                stamp(s, 2);")
+    k = sub(k, "                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }\n                lds_barrier();",
+            "                stamp(s + 1, 0);\n                if (s + 3 < nblk) vload(s + 3, ea);\n                if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }\n                stamp(s + 1, 1);\n                lds_barrier();\n                stamp(s + 1, 2);")
     k = sub(k, "            if (w == wstar) {  // last-column scores", "            if (false) {  // last-column scores")
+    k = sub(k, "                if (w == wstar) {\n                    const int t = j * kRows + lane;\n                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;\n                }", "")
     k = sub(k, "    if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;", "")
     # stamps land in the caller's char_prob buffer; the backtrack kernel is not launched
-    h = sub(h, "a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,",
-            "a.d_labels, pl->d_bits[ws], a.d_char_prob, pl->V, pl->prm.blank,")
+    h = sub(h, "a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,\n                       (pl->prm.flags",
+            "a.d_labels, pl->d_bits[ws], a.d_char_prob, pl->V, pl->prm.blank,\n                       (pl->prm.flags")
     h = sub(h, "    if ((rc = launch_backtrack(pl, a, want_seg, 0, st)) != CTCFA_OK) return rc;", "    (void)want_seg;")
     return k, h
 
@@ -135,9 +137,9 @@ def patch_btstamp(k, h):
     k = sub(k, "    // ---- phase 0: first maximum of the last column", "    const unsigned long long bt0 = __builtin_amdgcn_s_memtime();\n    // ---- phase 0: first maximum of the last column")
     k = sub(k, "    // ---- phase A (wave 0): the walk", "    const unsigned long long bt1 = __builtin_amdgcn_s_memtime();\n    // ---- phase A (wave 0): the walk")
     k = sub(k, "    // ---- phase B: per-frame outputs, lanes = frames", "    const unsigned long long bt2 = __builtin_amdgcn_s_memtime();\n    // ---- phase B: per-frame outputs, lanes = frames")
-    k = sub(k, "    if (!want_seg) return;\n    __threadfence_block();", "    const unsigned long long bt3 = __builtin_amdgcn_s_memtime();\n    if (!want_seg) return;\n    __threadfence_block();")
-    k = sub(k, "    score_utterances<kBtThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,\n                                 seg_start, seg_end, seg_score);\n}",
-            "    score_utterances<kBtThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,\n                                 seg_start, seg_end, seg_score);\n    __syncthreads();\n    const unsigned long long bt4 = __builtin_amdgcn_s_memtime();\n    if (tid == 0) { status_out[sd.seg_index] = (int)(bt1 - bt0); t_end_out[sd.seg_index] = (int)(bt2 - bt1); seg_start[sd.utt_off] = (double)(bt3 - bt2); seg_end[sd.utt_off] = (double)(bt4 - bt3); }\n}")
+    k = sub(k, "    if (!want_seg) return;\n    sync();", "    const unsigned long long bt3 = __builtin_amdgcn_s_memtime();\n    if (!want_seg) return;\n    sync();")
+    k = sub(k, "    score_utterances<kThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,\n                               seg_start, seg_end, seg_score, tid, tick);\n}",
+            "    score_utterances<kThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,\n                               seg_start, seg_end, seg_score, tid, tick);\n    sync();\n    const unsigned long long bt4 = __builtin_amdgcn_s_memtime();\n    if (tid == 0) { status_out[sd.seg_index] = (int)(bt1 - bt0); t_end_out[sd.seg_index] = (int)(bt2 - bt1); seg_start[sd.utt_off] = (double)(bt3 - bt2); seg_end[sd.utt_off] = (double)(bt4 - bt3); }\n}")
     return k, h
 
 

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 pkg = ge.build()
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # 0: the automatic choice (mixed 8-wave shape for config 3)
 syn = pkg.synthetic
 B, T, V, U, n = 512, 3000, 32, 22, 28
 lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n)
@@ -37,9 +37,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = d_cp.cpu().numpy().reshape(B, T)
 for seg in range(1):
-    st = raw[seg].view(np.uint64)[: (W + 1) * 16 * 3].reshape(W + 1, 16, 3).astype(np.int64)
+    NW = 8 if K == 0 else W + 1
+    roles = {0: "heavy s0", 2: "heavy s1", 4: "heavy s2", 6: "heavy s3", 1: "light s4", 3: "light s5", 5: "producer", 7: "idle"} \
+        if K == 0 else {w: ("producer" if w == W else f"stage {w}") for w in range(W + 1)}
+    st = raw[seg].view(np.uint64)[: NW * 16 * 3].reshape(NW, 16, 3).astype(np.int64)
     t_ref = st[0, 0, 0]
-    for w in range(W + 1):
+    for w in range(NW):
         rows = st[w]
         ok = (rows > 0).all(axis=1)
         if ok.sum() < 8:
@@ -49,6 +52,6 @@ for seg in range(1):
         work = np.median(rows[:, 1] - rows[:, 0])
         bar = np.median(rows[:, 2] - rows[:, 1])
         step = np.median(rows[1:, 0] - rows[:-1, 0])
-        role = "producer" if w == W else "compute "
-        print(f"wave {w:2d} {role}: step {step:.0f} cyc = work {work:.0f} + barrier {bar:.0f}   "
+        role = roles[w]
+        print(f"wave {w:2d} {role:9s}: step {step:.0f} cyc = work {work:.0f} + barrier {bar:.0f}   "
               f"(work ends at +{np.median(rows[:, 1] - st[0, ok, 0]):.0f} after wave 0 starts the step)  K={K} W={W}")
