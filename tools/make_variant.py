@@ -96,6 +96,11 @@ def patch_Q2(k, h):
     return sub(k, PRIO_ANCHOR, "    if (my.role == kRoleHeavy) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(0);"), h
 
 
+def patch_Q4(k, h):
+    """light tiles above heavy ones (3 / 2)"""
+    return sub(k, PRIO_ANCHOR, "    if (my.role == kRoleHeavy) __builtin_amdgcn_s_setprio(2);\n    else __builtin_amdgcn_s_setprio(3);"), h
+
+
 def patch_Q3(k, h):
     """heavy: later stages above earlier ones (3/2), light 1"""
     return sub(k, PRIO_ANCHOR, "    if (my.role != kRoleHeavy) __builtin_amdgcn_s_setprio(1);\n    else if (w >= 2) __builtin_amdgcn_s_setprio(3);\n    else __builtin_amdgcn_s_setprio(2);"), h
@@ -143,7 +148,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"btwalk": patch_btwalk, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
