@@ -133,6 +133,9 @@ FillFn select_fill(int KH, int KL, int VP) {
             case 48: return fill_for_k<48>(KH);
             case 56: return fill_for_k<56>(KH);
             case 64: return fill_for_k<64>(KH);
+            case 80: return fill_for_k<80>(KH);
+            case 96: return fill_for_k<96>(KH);
+            case 112: return fill_for_k<112>(KH);
             case 128: return fill_for_k<128>(KH);
             default: return nullptr;
         }
@@ -143,6 +146,9 @@ FillFn select_fill(int KH, int KL, int VP) {
         case 48: return fill_mixed<48>(KH);
         case 56: return fill_mixed<56>(KH);
         case 64: return fill_mixed<64>(KH);
+        case 80: return fill_mixed<80>(KH);
+        case 96: return fill_mixed<96>(KH);
+        case 112: return fill_mixed<112>(KH);
         case 128: return fill_mixed<128>(KH);
         default: return nullptr;
     }
@@ -236,6 +242,11 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
     double best_cost = -1.0;
     ShapeChoice best{0, 0, false};
     const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
+    // Wide pitches (65..128-entry vocabularies): their conflict-laden gathers need rows long enough
+    // to hide the LDS latency, and measured a second round of workgroups costs far more than the
+    // model says (V = 76: K=5 in one round 467 us, K=2 in two rounds 757 us).  First look only at
+    // shapes that hold the whole batch at once; fall back to everything if there is none.
+    bool single_round_only = VP > 64;
     auto instr = [](int K) { return 9.5 * K + 7.0; };
     auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
         const int lds = lds_bytes_fill(stages, VP);
@@ -246,6 +257,7 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
         const int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
         const int g_eff = std::min(G, wg_per_cu_needed);
         const int rounds = (wg_per_cu_needed + G - 1) / G;
+        if (single_round_only && rounds > 1) return;
         const double wave_bound = 4.7 * instr(K);
         double simd_bound;
         if (mixed) {
@@ -273,6 +285,16 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
         consider(K, W, false, W, W + 1);
         if (!force_k && allow_mixed && W == 5 && (K == 2 || K == 4)) consider(K, W, true, 6, 8);
         if (!force_k && allow_mixed && W == 6) consider(K, W, false, 6, 8);  // six equal tiles on 8 waves
+    }
+    if (!best.K && single_round_only) {
+        single_round_only = false;
+        for (int K : kKs) {
+            if (force_k && K != force_k) continue;
+            const int padded = roundup(Cmax, K);
+            const int W = (padded + 64 * K - 1) / (64 * K);
+            if (W > 15 || (K >= 10 && W > 4)) continue;
+            consider(K, W, false, W, W + 1);
+        }
     }
     if (!best.K) return false;
     *out = best;
@@ -416,7 +438,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // LDS row pitch: the vocabulary rounded up to a compiled size.  Character vocabularies of
     // wav2vec2 models sit between 32 and 64 (the reference's Spanish model: 38 tokens), where
     // a pitch of 64 would cost a second workgroup per CU.
-    pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64 : 128;
+    pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
+           : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
     pl->have_utt = (U != nullptr);
 
     int Cmax = 2, Tmax = 1;

@@ -344,21 +344,59 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if (s + 2 < nblk) { write_chunk(s + 2, 0, eb); publish_flag(); }
                 lds_barrier();
             }
-        } else {
-            // wide vocabulary: several chunks per block, loaded and written within the step
-            float e[CH];
-            auto stage_block = [&](int jb) {
-#pragma unroll 1
-                for (int p0 = 0; p0 < PASSES; p0 += CH) {
-                    load_chunk(jb, p0, e);
-                    write_chunk(jb, p0, e);
+        } else if constexpr (VP > 64) {
+            // ---- character vocabularies between 65 and 128 entries (e.g. 76 for French): a row per
+            // pass, lane i holds entries i and 64 + i, loads run a whole block ahead of their use
+            // (one register set, as above); lane 0 also writes the start-column pseudo entry.
+            const int sv0 = lane < V ? lane : V - 1;
+            const int sv1 = lane + 64 < V ? lane + 64 : V - 1;
+            auto wload = [&](int jb, float (&e0)[kRows], float (&e1)[kRows]) {
+                const int t0 = jb * kRows + 1;
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    int t = t0 + r;
+                    t = t < T ? t : T - 1;
+                    const unsigned char* rowp = lpz_bytes + static_cast<uint32_t>(t * V) * 4u;
+                    e0[r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv0) * 4u);
+                    e1[r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv1) * 4u);
                 }
             };
-            stage_block(0);
+            auto wwrite = [&](int jb, const float (&e0)[kRows], const float (&e1)[kRows]) {
+                unsigned char* slot = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES);
+                // lanes past the vocabulary park their stores on the pad entry VP + 1
+                unsigned char* d0 = slot + static_cast<uint32_t>((lane < V ? lane : VP + 1) * 8);
+                unsigned char* d1 = slot + static_cast<uint32_t>((lane + 64 < V ? lane + 64 : VP + 1) * 8);
+                unsigned char* dp = slot + static_cast<uint32_t>((lane == 0 ? VP : VP + 1) * 8);
+                const int t0 = jb * kRows + 1;
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    const float lb = (blank < 64)
+                                         ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e0[r]), blank & 63))
+                                         : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1[r]), blank & 63));
+                    const bool valid = (t0 + r) < T;  // uniform
+                    notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
+                    float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
+                    float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
+                    float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                    if (!valid) {
+                        v0 = make_float2(0.f, 0.f);
+                        v1 = v0;
+                        vp = make_float2(-__builtin_inff(), 0.0f);
+                    }
+                    *reinterpret_cast<float2*>(d0 + r * (PITCH * 8)) = v0;
+                    *reinterpret_cast<float2*>(d1 + r * (PITCH * 8)) = v1;
+                    *reinterpret_cast<float2*>(dp + r * (PITCH * 8)) = vp;
+                }
+            };
+            float ea[kRows], eb[kRows];
+            wload(0, ea, eb);
+            wwrite(0, ea, eb);
+            if (1 < nblk) wload(1, ea, eb);
             lds_barrier();
             publish_flag();
             for (int s = 0; s < nsteps; ++s) {
-                if (s + 1 < nblk) { stage_block(s + 1); publish_flag(); }
+                if (s + 1 < nblk) { wwrite(s + 1, ea, eb); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
+                if (s + 2 < nblk) wload(s + 2, ea, eb);
                 lds_barrier();
             }
         }

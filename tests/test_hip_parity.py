@@ -92,7 +92,7 @@ def test_every_lane_tile_width(pkg, oracle, engine, K):
     plan.close()
 
 
-@pytest.mark.parametrize("V", [5, 29, 32, 33, 38, 40, 45, 48, 52, 56, 57, 63, 64, 100, 128])
+@pytest.mark.parametrize("V", [5, 29, 32, 33, 38, 40, 45, 48, 52, 56, 57, 63, 64, 65, 76, 80, 81, 96, 97, 100, 112, 113, 128])
 def test_vocabulary_sizes(pkg, oracle, V):
     syn = pkg.synthetic
     segs = [syn.make_segment(200 + s + V, T, V, U, n) for s, (T, U, n) in
@@ -513,7 +513,7 @@ def _fuzz_segment(rng, V, blank, Tmax):
     return lpz, gt, ub
 
 
-@pytest.mark.parametrize("V,blank", [(5, 0), (17, 3), (32, 0), (33, 32), (38, 0), (47, 46), (55, 9), (63, 62), (64, 1), (100, 0), (128, 127)])
+@pytest.mark.parametrize("V,blank", [(5, 0), (17, 3), (32, 0), (33, 32), (38, 0), (47, 46), (55, 9), (63, 62), (64, 1), (76, 70), (90, 3), (100, 0), (111, 64), (128, 127)])
 @pytest.mark.parametrize("flags", [dict(), dict(preamble_transition_cost_zero=False), dict(backtrack_from_max_t=True)])
 def test_fuzz_shapes_vocabularies_and_flags(pkg, oracle, V, blank, flags):
     """Random ragged batches over vocabulary sizes (all three LDS row pitches), blank positions,
