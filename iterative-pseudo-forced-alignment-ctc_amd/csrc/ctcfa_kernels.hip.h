@@ -1,6 +1,6 @@
 // ctcfa_kernels.hip.h -- gfx950 device code of the CTC forced-alignment engine.
 //
-// What is computed (per segment, S = 1 labels, un-windowed regime T <= min_window_size):
+// What is computed (per segment, S = 1 labels):
 //   table[t,c] = max( table[t-1,c-1] + lpz[t,g_c],  table[t-1,c] + max(lpz[t,blank], lpz[t,g_c]),  -1e9 )
 // in fp32, exactly the recurrence of ctc-segmentation 1.7.1's cython_fill_table
 // (requirements.txt:13; reached from src/iterative_utterance_alignment.py:216), plus the
@@ -9,20 +9,29 @@
 // That predicate is evaluated at fill time, while all four operands are in registers,
 // and kept as ONE BIT per cell; the fp32 trellis itself never leaves the chip.
 //
-// Mapping (CDNA4, 64-wide waves, no MFMA: this is a max-plus scan, not a contraction):
-//   * one workgroup per segment, W waves; wave w owns padded columns [w*64K, (w+1)*64K),
-//     lane l owns K consecutive columns -> the c-1 neighbour is in-lane for k>0 and one
-//     DPP wave_shr:1 for k==0; lane 0 takes the previous wave's last column from LDS;
-//   * time runs in blocks of R=32 rows; wave w works on block (s - w) in step s (a skewed
-//     pipeline, one s_barrier per step) so that the cross-wave dependency is a block old;
+// Kernels:
+//   fill_kernel<KH,KL,VP>   T <= min_window_size, vocabulary <= 128: the hot one
+//   fill_gather_kernel      same, vocabulary > 128 (no LDS staging of vocabulary rows)
+//   backtrack_kernel        end cell, walk over the decision bits, per-frame outputs, scores
+//   windowed_kernel         T > min_window_size: the package's windowed regime, literally
+//
+// Mapping of fill_kernel (CDNA4, 64-wide waves, no MFMA: a max-plus scan is not a contraction):
+//   * one workgroup per segment; its padded columns are cut into tiles, a compute wave owns
+//     one tile, lane l owns K consecutive columns -> the c-1 neighbour is in-lane for k>0 and
+//     one DPP wave_shr:1 for k==0; lane 0 takes the previous tile's last column from an LDS
+//     ring.  A role table (FillRoles) says what each wave of the workgroup is: heavy tile,
+//     light tile, producer, idle;
+//   * time runs in blocks of R=32 rows; stage l works on block (s - l) in step s (a skewed
+//     pipeline, one s_barrier per step) so that the cross-tile dependency is a block old;
 //   * emission rows are staged once per workgroup through an LDS ring as (e, m) pairs,
-//     m = max(lb, e, -1e9), row pitch VP+1 entries: a gather is one ds_read_b64 whose
-//     32 x 8 B row covers all 64 banks exactly once -> conflict-free for any label mix;
-//     entry VP is the "start column" pseudo-label (e = -inf, m = 0) that makes column 0
+//     m = max(lb, e, -1e9), row pitch VP+2 entries; a gather is one ds_read_b64; entry VP is
+//     the "start column" pseudo-label (e = -inf, m = 0) that makes column 0
 //     (ground_truth == -1) and the left padding reproduce table[t,0];
 //   * decisions are shifted into a per-(lane,k) register (v_alignbit) and stored every
 //     32 rows as words bits[block][column]; HBM traffic per segment is
-//     4*T*V (emissions, once) + T*Cpad/8 (bits) + 4*T (last-column scores).
+//     4*T*V (emissions, once) + T*Cpad/8 (bits) + 4*T (last-column scores);
+//   * blocks that cannot matter are skipped exactly (dead zone behind the end cell's cone;
+//     the -1e9 zone above the diagonal while every emission so far is <= 0).
 #pragma once
 #include <hip/hip_runtime.h>
 #ifndef CTCFA_PF
