@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "../../include/ctcfa.h"
 
 using ctcfa::BtParams;
@@ -691,22 +693,28 @@ int check_args(ctcfa_plan* pl, const RunArgs& a, bool* want_seg) {
     return CTCFA_OK;
 }
 
-int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st) {
+// start / stop: events carried by the kernel's own dispatch packet (hipExtLaunchKernel) -- timing and
+// cross-stream hand-over without separate event-record packets between two kernels
+int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEvent_t start = nullptr,
+                hipEvent_t stop = nullptr) {
     if (pl->gather) {
-        hipLaunchKernelGGL(ctcfa::fill_gather_kernel, dim3(pl->B), dim3(64 * pl->W), pl->lds_fill, st, pl->d_segs,
-                           a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
-                           pl->roles.cpad);
+        hipExtLaunchKernelGGL(ctcfa::fill_gather_kernel, dim3(pl->B), dim3(64 * pl->W), pl->lds_fill, st, start, stop,
+                              0, pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V,
+                              pl->prm.blank, pl->roles.cpad);
         HIP_TRY(pl->eng, hipGetLastError());
         return CTCFA_OK;
     }
-    hipLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, pl->d_segs, a.d_lpz,
-                       a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
-                       (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0, pl->d_roles);
+    hipExtLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, start, stop, 0,
+                          pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
+                          (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0,
+                          (const ctcfa::FillRoles*)pl->d_roles);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }
 
-int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hipStream_t st) {
+int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hipStream_t st,
+                     hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+    const bool windowed = !pl->win_list.empty();
     BtParams bp;
     bp.V = pl->V;
     bp.blank = pl->prm.blank;
@@ -718,9 +726,10 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
                            pl->d_lastcol[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
                            want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
-    hipLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st, ba);
+    hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st, start,
+                          windowed ? nullptr : stop, 0, ba);
     HIP_TRY(pl->eng, hipGetLastError());
-    if (!pl->win_list.empty()) {
+    if (windowed) {
         ctcfa::WinParams wp;
         wp.V = pl->V;
         wp.blank = pl->prm.blank;
@@ -730,11 +739,12 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.max_window = pl->prm.max_window_size;
         wp.lds_bytes = pl->lds_win;
         wp.dur = pl->prm.index_duration;
-        hipLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
-                           pl->lds_win, st, pl->d_segs, pl->d_win_list, a.d_lpz, a.d_labels,
-                           want_seg ? a.d_utt_begin : nullptr, pl->d_win_table, pl->d_win_offs, wp, a.d_fol,
-                           a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
-                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status);
+        hipExtLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
+                              pl->lds_win, st, nullptr, stop, 0, (const SegDesc*)pl->d_segs,
+                              (const int32_t*)pl->d_win_list, a.d_lpz, a.d_labels,
+                              want_seg ? a.d_utt_begin : (const int32_t*)nullptr, pl->d_win_table, pl->d_win_offs, wp,
+                              a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
+                              want_seg ? a.d_seg_score : (double*)nullptr, a.d_t_end, a.d_status);
         HIP_TRY(pl->eng, hipGetLastError());
     }
     return CTCFA_OK;
@@ -761,17 +771,9 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
     }
     const bool timed = pl->ev_slots && (pl->run_counter++ % pl->ev_stride == 0);
     hipEvent_t* ev = timed ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
-    if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
-    if ((rc = launch_fill(pl, a, 0, st)) != CTCFA_OK) return rc;
-    if (ev) {
-        HIP_TRY(eng, hipEventRecord(ev[1], st));
-        HIP_TRY(eng, hipEventRecord(ev[2], st));
-    }
-    if ((rc = launch_backtrack(pl, a, want_seg, 0, st)) != CTCFA_OK) return rc;
-    if (ev) {
-        HIP_TRY(eng, hipEventRecord(ev[3], st));
-        pl->ev_runs++;
-    }
+    if ((rc = launch_fill(pl, a, 0, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr)) != CTCFA_OK) return rc;
+    if ((rc = launch_backtrack(pl, a, want_seg, 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr)) != CTCFA_OK) return rc;
+    if (ev) pl->ev_runs++;
     return CTCFA_OK;
 }
 
@@ -792,8 +794,8 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
         HIP_TRY(eng, hipMalloc(&pl->d_bits[1], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
         HIP_TRY(eng, hipMalloc(&pl->d_lastcol[1], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
         for (int q = 0; q < 2; ++q) {
-            HIP_TRY(eng, hipEventCreateWithFlags(&pl->ev_fill_done[q], hipEventDisableTiming));
-            HIP_TRY(eng, hipEventCreateWithFlags(&pl->ev_bt_done[q], hipEventDisableTiming));
+            HIP_TRY(eng, hipEventCreate(&pl->ev_fill_done[q]));  // (kernel-attached events carry timestamps)
+            HIP_TRY(eng, hipEventCreate(&pl->ev_bt_done[q]));
         }
         HIP_TRY(eng, hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
     }
@@ -808,15 +810,12 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     // event of run k is still untouched when run k+2 waits on it.)
     const bool timed = pl->ev_slots >= 4 && (pl->run_counter++ % pl->ev_stride == 0);
     hipEvent_t* ev = timed ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
-    if (ev) HIP_TRY(eng, hipEventRecord(ev[0], st));
-    if ((rc = launch_fill(pl, a, q, st)) != CTCFA_OK) return rc;
+    // the events ride on the kernels' own dispatch packets: nothing else enters the queues
     hipEvent_t fill_done = ev ? ev[1] : pl->ev_fill_done[q];
-    HIP_TRY(eng, hipEventRecord(fill_done, st));
+    if ((rc = launch_fill(pl, a, q, st, ev ? ev[0] : nullptr, fill_done)) != CTCFA_OK) return rc;
     HIP_TRY(eng, hipStreamWaitEvent(pl->side, fill_done, 0));
-    if (ev) HIP_TRY(eng, hipEventRecord(ev[2], pl->side));
-    if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side)) != CTCFA_OK) return rc;
     hipEvent_t bt_done = ev ? ev[3] : pl->ev_bt_done[q];
-    HIP_TRY(eng, hipEventRecord(bt_done, pl->side));
+    if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side, ev ? ev[2] : nullptr, bt_done)) != CTCFA_OK) return rc;
     if (ev) pl->ev_runs++;
     pl->bt_done_ev[q] = bt_done;
     pl->bt_pending[q] = true;
