@@ -6,8 +6,8 @@
 # Run on the MI355X box from the repo root:  tools/collect_traffic.sh  -> gpurun_out/pmc_traffic.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --cpu-sample 0 --serial > gpurun_out/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 6 --warmup 2 --cpu-sample 0 --serial > gpurun_out/pmc_write.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --spinup-steps 0 --cpu-sample 0 --serial > gpurun_out/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 6 --warmup 2 --spinup-steps 0 --cpu-sample 0 --serial > gpurun_out/pmc_write.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, glob, collections, json
 out = {}

@@ -5,7 +5,7 @@ rocprofv3 -L 2>/dev/null | grep -oE "SQ_[A-Z_0-9]*(LDS|VALU)[A-Z_0-9]*" | sort -
 for K in $1; do
  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"; do
   rm -rf gpurun_out/pmcx
-  rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --cpu-sample 0 --no-check --serial --cols-per-lane $K > gpurun_out/pmcx.log 2>&1 || { tail -5 gpurun_out/pmcx.log; continue; }
+  rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --spinup-steps 0 --cpu-sample 0 --no-check --serial --cols-per-lane $K > gpurun_out/pmcx.log 2>&1 || { tail -5 gpurun_out/pmcx.log; continue; }
   python3 - "$K" <<'PY'
 import csv,glob,sys,collections
 f=glob.glob('gpurun_out/pmcx/*/*_counter_collection.csv')

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for item in $1; do L=${item%%:*}; K=${item##*:}
   rm -rf gpurun_out/pmcx
-  CTCFA_LIB=$PWD/$L rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --cpu-sample 0 --no-check --cols-per-lane $K > gpurun_out/pmcx.log 2>&1
+  CTCFA_LIB=$PWD/$L rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --spinup-steps 0 --cpu-sample 0 --no-check --cols-per-lane $K > gpurun_out/pmcx.log 2>&1
   python3 - "$L" "$K" <<'PY'
 import csv,glob,sys,collections
 f=glob.glob('gpurun_out/pmcx/*/*_counter_collection.csv')
