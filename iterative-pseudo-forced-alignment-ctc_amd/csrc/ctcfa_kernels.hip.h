@@ -118,7 +118,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // order on gfx9, so one wave doing both pays an HBM write round trip in every load wait.)
 // dynamic LDS = (W+1) slots * kRows * (VP+1) * 8  +  boundary columns  +  small buffers.
 // ---------------------------------------------------------------------------------------
-template <int KH, int KL, int VP>
+template <int KH, int KL, int VP, bool CK = false>
 __global__ void __launch_bounds__((KH >= 10) ? 320 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
@@ -484,6 +484,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const int t = j * kRows + lane;
                     if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
                 }
+                if constexpr (CK) {  // the table row this block would have ended in
+                    uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) bp[k] = __float_as_uint(kProbMax);
+                }
                 lds_barrier();
                 continue;
             }
@@ -546,11 +551,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const float a = pl + em[k].x;
                     const float b = pk + em[k].y;
                     const float nw = max3f(a, b, kProbMax);
-                    const float rsw = em[k].x - (nw - pl);
-                    const float rst = em[k].y - (nw - pk);
-                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
-                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
-                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
+                    if constexpr (!CK) {
+                        const float rsw = em[k].x - (nw - pl);
+                        const float rst = em[k].y - (nw - pk);
+                        // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                        const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                        dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
+                    }
                     prev[k] = nw;
                 }
                 if ((i + 1) % 4 == 0) pub4.x = prev[K - 1];
@@ -564,12 +571,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 // consumed at the end of the block, and LLVM otherwise sinks the residual math of
                 // all 32 rows down to that store, keeping every operand alive (hundreds of spills).
 #pragma unroll
-                for (int k = 0; k < K; ++k) asm volatile("" : "+v"(dec[k]));
+                for (int k = 0; k < K; ++k) {
+                    if constexpr (CK) asm volatile("" : "+v"(prev[k]));  // (keeps the rows apart for the scheduler)
+                    else asm volatile("" : "+v"(dec[k]));
+                }
             }
             // decision words of this block (fire and forget: this wave never waits on vmcnt)
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
 #pragma unroll
-            for (int k = 0; k < K; ++k) bp[k] = dec[k];
+            for (int k = 0; k < K; ++k) bp[k] = CK ? __float_as_uint(prev[k]) : dec[k];
             if (w == wstar) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
                 const int t = j * kRows + lane;
                 if (lane < kRows && t >= 1 && t < T)
@@ -744,8 +754,28 @@ struct BtParams {
     uint32_t flags;
     int L;            // score_min_mean_over_L
     int rec_bytes;    // bytes reserved for rec[] (multiple of 16) in dynamic LDS
+    int lab_bytes;    // checkpoint mode: bytes reserved for the label copy that follows rec[] (multiple of 16), else 0
     double dur;       // index_duration
 };
+
+// Checkpoint mode (fill_kernel<.., CK = true>, V <= 64): the fill stores no decisions, only the
+// table row every 32-row block ends in.  The backtrack recomputes what it needs: the path drops at
+// most one column per row, so inside a block it stays within 32 columns of where it enters and
+// every cell it visits depends on 64 columns of the previous block's last row -- one wave, lane i
+// = column (pc - i), runs the fill's recurrence AND the residual comparison over those 32 rows
+// (same operations in the same order: bit-identical decisions), ~10 % of the cells the fill
+// touches.  Lanes whose left neighbours are outside the window go wrong one column per row; the
+// path is always ahead of that front (row r: garbage in lanes >= 63 - r, path in lanes <= 31 - r).
+// Waves 1-3 stage the emission rows of the coming blocks as (e, m) pairs in LDS meanwhile (row
+// pitch PB entries, the last one the start column's pseudo label, as in the fill).  One slot: wave
+// 0 takes a block's 32 pairs into registers at once, then the slot is free for the next block.
+// It shares its LDS with the char_probs copy of the later phases -- the kernel has to stay under
+// 15.8 KB of LDS to sit beside two fill workgroups on a CU.
+
+__device__ __forceinline__ float dpp_wave_shl1(float src) {
+    // lane i <- src[lane i+1]; lane 63 <- 0 (bound_ctrl: the DPP folds into the consuming VALU op)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x130, 0xf, 0xf, true));
+}
 
 __device__ __forceinline__ double np_pairwise_sum_le128(const float* a, int n) {
     // NumPy's pairwise summation for n <= 128 (fp64 accumulate of fp32-exact values), LDS input
@@ -856,7 +886,7 @@ struct BtArgs {
 // NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
 // `sync` separates the phases, `tick` is called between slices of work (the fused wave has to
 // take part in the fill workgroup's barriers while it lives).
-template <int NT, class Sync, class Tick>
+template <int NT, int PB, class Sync, class Tick>
 __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& sd, int tid, unsigned char* smem,
                                                float* red_v, int* red_t, int* sh_misc, Sync sync, Tick tick) {
     const BtParams& p = a.p;
@@ -874,8 +904,11 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     int32_t* __restrict__ t_end_out = a.t_end_out;
     int32_t* __restrict__ status_out = a.status_out;
     constexpr int kThreads = NT;
+    constexpr bool CK = PB > 0;
     int2* rec = reinterpret_cast<int2*>(smem);                   // per block: (entry column, switch mask)
-    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes);   // char_probs of this segment
+    int32_t* labs = reinterpret_cast<int32_t*>(smem + p.rec_bytes);             // checkpoint mode: label copy
+    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes + p.lab_bytes);    // char_probs of this segment
+    float2* ering = reinterpret_cast<float2*>(cps);              // checkpoint mode, phase A: [32][PB] (e, m)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = kThreads / 64;
@@ -941,8 +974,220 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     const int nblk = (T - 1 + kRows - 1) / kRows;
     for (int j = tid; j < nblk; j += kThreads) rec[j] = make_int2(-1, 0);
     for (int c = tid; c < C; c += kThreads) fol[c] = 0;
+    if constexpr (CK) {
+        for (int c = tid; c < C; c += kThreads) labs[c] = seg_lab[c];
+    }
     sync();
 
+    if constexpr (CK) {
+        // ---- phase A, checkpoint mode: all four waves --------------------------------------
+        // (per-block barriers order LDS only: the producers' loads and the checkpoint prefetches
+        // stay in flight across them)
+        float bv = red_v[0];
+        int bt = red_t[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) {
+            const float ov = red_v[q];
+            const int ot = red_t[q];
+            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
+                bv = ov;
+                bt = ot;
+            }
+        }
+        int t_end = __builtin_amdgcn_readfirstlane(bt);
+        if (p.flags & 4u) t_end = T - 1;
+        int pc = C - 1 + shift;
+        if (t_end >= 1) {
+            const int jstart = (t_end - 1) >> 5;
+            if (wave != 0) {
+                // ======== producers: block jb is staged by wave 1 + jb % 3; its loads are issued
+                // three steps before the block is walked and written to the ring one step before.
+                // lane v < V stages vocabulary entry v of every row; lane V (if there is one) the
+                // start column's pseudo entry.  Everything sits under ONE lane mask per block: a
+                // put() has to fit inside the step of the block that is being walked.
+                float e[kRows];
+                const bool preamble = (p.flags & 2u) != 0;
+                const bool is_pseudo = lane == V;             // no such lane when V == 64
+                const int woff = is_pseudo ? PB - 1 : lane;
+                auto issue = [&](int jb) {
+                    if (lane < V) {
+#pragma unroll
+                        for (int r = 0; r < kRows; ++r) {
+                            int t = jb * kRows + 1 + r;
+                            t = t < T ? t : T - 1;   // rows past the end: decisions nobody reads
+                            e[r] = seg_lpz[(int64_t)t * V + lane];
+                        }
+                    }
+                };
+                auto put = [&](int jb) {
+                    float2* slot = ering + woff;
+                    if (lane <= V) {
+#pragma unroll
+                        for (int r = 0; r < kRows; ++r) {
+                            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
+                            const float m = max3f(lb, e[r], kProbMax);
+                            const float pm = preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax);  // start column's stay step
+                            slot[r * PB] = make_float2(is_pseudo ? -__builtin_inff() : e[r], is_pseudo ? pm : m);
+                        }
+                    }
+                    if (V == 64 && lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < kRows; ++r) {
+                            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
+                            ering[r * PB + PB - 1] = make_float2(-__builtin_inff(),
+                                                                 preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                        }
+                    }
+                };
+                auto mine = [&](int jb) { return jb >= 0 && 1 + jb % 3 == wave; };
+                if (mine(jstart)) {
+                    issue(jstart);
+                    put(jstart);
+                }
+                if (mine(jstart - 1)) issue(jstart - 1);
+                if (mine(jstart - 2)) issue(jstart - 2);
+                for (int j = jstart; j >= 0; --j) {
+                    lds_barrier();  // A: block j is in the slot
+                    lds_barrier();  // B: wave 0 has it in registers
+                    if (mine(j - 1)) put(j - 1);
+                    if (mine(j - 3)) issue(j - 3);
+                }
+            } else {
+                // ======== wave 0: recompute the block's decisions, then walk it ==================
+                int j = jstart;
+                int b0 = 31 - ((t_end - 1) & 31);
+                const uint32_t* seg_bits = bits + sd.bits_off;
+                // table row the block starts from = what the fill stored for block jb - 1
+                // (row 0: table[0,0] = 0, table[0,c>0] = -1e9), requested kDepth blocks ahead for
+                // the 192 columns the entry column can still lie in, re-based on arrival
+                constexpr int kDepth = 4;
+                // (branch-free and unconditional: a load under control flow makes the compiler wait
+                // for every outstanding load at the join; what must not be used is replaced on arrival)
+                auto fetch = [&](int jb, int base, int part) -> uint32_t {
+                    const int col = base - 64 * part - lane;
+                    const int64_t idx = (jb >= 1 && col >= 0) ? (int64_t)(jb - 1) * p.Cpad + col : 0;
+                    return seg_bits[idx];
+                };
+                uint32_t pf[kDepth][3];
+                int pbase[kDepth];
+#pragma unroll
+                for (int u = 0; u < kDepth; ++u) {
+                    pbase[u] = pc;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - u, pc, q);
+                }
+#ifdef CTCFA_CK_STAMP
+                unsigned long long ck_s[4] = {0, 0, 0, 0};
+#define CK_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define CK_ACC(i, a, b) ck_s[i] += (b) - (a)
+#else
+#define CK_T(x)
+#define CK_ACC(i, a, b)
+#endif
+                while (j >= 0) {
+#pragma unroll
+                    for (int u = 0; u < kDepth; ++u) {
+                        if (j < 0) break;
+                        CK_T(ck0);
+                        const int cstart = pc;
+                        const int src = (pbase[u] - pc) + lane;  // 0 .. 191
+                        const uint32_t f0 = __shfl(pf[u][0], src & 63);
+                        const uint32_t f1 = __shfl(pf[u][1], src & 63);
+                        const uint32_t f2 = __shfl(pf[u][2], src & 63);
+                        float prev = __uint_as_float((src < 64) ? f0 : (src < 128) ? f1 : f2);
+                        {
+                            const int col = pc - lane;
+                            if (j == 0) prev = col - shift <= 0 ? 0.0f : kProbMax;  // table row 0
+                            if (col < 0) prev = 0.0f;                                // left of the padded table
+                        }
+                        pbase[u] = pc;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - kDepth, pc, q);
+
+                        const int c = pc - lane - shift;           // label column of this lane
+                        const int lab = c <= 0 ? PB - 1 : labs[c];  // c < C: the path never sits right of C-1
+                        const float2* erow = ering + lab;
+                        float2 emr[kRows];
+                        lds_barrier();  // A: block j is in the slot
+#pragma unroll
+                        for (int i = 0; i < kRows; ++i) emr[i] = erow[i * PB];
+                        lds_barrier();  // B: the slot may be overwritten (waits for the reads above)
+                        uint32_t dec = 0u;
+#ifdef CTCFA_CK_STAMP
+                        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+                        asm volatile("" : "+v"(prev));
+#endif
+                        CK_T(ck1);
+#pragma unroll
+                        for (int i = 0; i < kRows; ++i) {
+                            const float ee = emr[i].x, m = emr[i].y;
+                            const float pl = dpp_wave_shl1(prev);
+                            const float a = pl + ee;
+                            const float b = prev + m;
+                            const float nw = max3f(a, b, kProbMax);
+                            const float rsw = ee - (nw - pl);
+                            const float rst = m - (nw - prev);
+                            const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                            dec = __builtin_amdgcn_alignbit(dec, __float_as_uint(d), 31);
+                            prev = nw;
+                        }
+                        uint32_t wl = c <= 0 ? 0u : dec;     // start column and left of it: STAY
+#ifdef CTCFA_CK_STAMP
+                        asm volatile("" : "+v"(wl));
+#endif
+                        CK_T(ck2);
+                        uint32_t S = 0;
+                        int pidx = 0;
+                        int bb = b0;
+                        if (bb < kRows) {
+                            uint32_t tmp;
+                            asm volatile(
+                                "1:\n\t"
+                                "s_nop 3\n\t"
+                                "v_readlane_b32 %3, %4, %1\n\t"
+                                "s_lshr_b32 %3, %3, %2\n\t"
+                                "s_cmp_eq_u32 %3, 0\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_ff1_i32_b32 %3, %3\n\t"
+                                "s_add_i32 %3, %3, %2\n\t"
+                                "s_bitset1_b32 %0, %3\n\t"
+                                "s_add_i32 %2, %3, 1\n\t"
+                                "s_add_i32 %1, %1, 1\n\t"
+                                "s_cmp_lt_i32 %2, 32\n\t"
+                                "s_cbranch_scc1 1b\n\t"
+                                "2:"
+                                : "+s"(S), "+s"(pidx), "+s"(bb), "=&s"(tmp)
+                                : "v"(wl)
+                                : "scc");
+                        }
+                        pc -= pidx;
+                        if (lane == 0) rec[j] = make_int2(cstart, (int)S);
+                        --j;
+                        b0 = 0;
+                        CK_T(ck3);
+                        CK_T(ck4);
+                        CK_ACC(0, ck0, ck1);
+                        CK_ACC(1, ck1, ck2);
+                        CK_ACC(2, ck2, ck3);
+                        CK_ACC(3, ck3, ck4);
+                    }
+                }
+#ifdef CTCFA_CK_STAMP
+                if (lane == 0 && a.seg_start) {
+                    for (int q = 0; q < 4; ++q) a.seg_start[sd.utt_off + q] = (double)ck_s[q];
+                    a.seg_start[sd.utt_off + 4] = (double)(jstart + 1);
+                }
+#endif
+            }
+        }
+        if (wave == 0 && lane == 0) {
+            sh_misc[0] = t_end;
+            sh_misc[1] = (pc - shift > 0);  // reached t == 0 in a label column: the package's IndexError
+        }
+#ifdef CTCFA_CK_STAMP
+        return;
+#endif
+    } else
     // ---- phase A (wave 0): the walk, one scalar step per run of STAYs ----------------------
     if (wave == 0) {
         float bv = red_v[0];
@@ -1116,6 +1361,7 @@ struct WaveSync {  // one wave: program order + completed memory operations is a
     }
 };
 
+template <int PB>  // 0: decision words from the fill; 33 / 65: checkpoint mode, V <= 32 / V <= 64
 __global__ void __launch_bounds__(kBtThreads)
 backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1123,7 +1369,7 @@ backtrack_kernel(BtArgs a) {
     __shared__ int red_t[kBtThreads / 64];
     __shared__ int sh_misc[2];  // [0] t_end, [1] bad
     const SegDesc sd = a.segs[blockIdx.x];
-    backtrack_body<kBtThreads>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
+    backtrack_body<kBtThreads, PB>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
 }
 
 

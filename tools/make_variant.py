@@ -9,6 +9,7 @@ bench.py --no-check or tools/stamps.py):
     A      no cross-wave boundary LDS traffic in the row loop (no bnd read, no publish)
     C      no emission gathers (operands derived from registers)
     D      recurrence only: drop the residual/decision math (4 VALU per cell)
+    E      no decision math, checkpoint rows stored instead of decision words (3 VALU per cell)
     stamp  s_memtime stamps around compute / barrier of every step (see tools/stamps.py);
            host passes char_prob as the stamp buffer and skips the backtrack kernel
 """
@@ -51,6 +52,18 @@ def patch_D(k, h):
                     const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
                     dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);""",
             "                    dec[k] ^= __float_as_uint(nw);")
+    return k, h
+
+
+def patch_E(k, h):
+    """no decision math at all; the block's store writes the tile's last table row (what a
+    backtrack that recomputes its own 64-column windows would need)"""
+    k = sub(k, """                    const float rsw = em[k].x - (nw - pl);
+                    const float rst = em[k].y - (nw - pk);
+                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);""", "")
+    k = sub(k, "for (int k = 0; k < K; ++k) bp[k] = dec[k];", "for (int k = 0; k < K; ++k) bp[k] = __float_as_uint(prev[k]);")
     return k, h
 
 
@@ -148,7 +161,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"E": patch_E, "btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
