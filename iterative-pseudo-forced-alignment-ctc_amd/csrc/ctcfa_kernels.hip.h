@@ -943,6 +943,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         return;
     }
 
+#ifdef CTCFA_BT_PHASES
+    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 0: first maximum of the last column (lastMax/lastArgMax of the fill) --------
     {
         const float* lc = lastcol + sd.frm_off;
@@ -978,6 +981,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         for (int c = tid; c < C; c += kThreads) labs[c] = seg_lab[c];
     }
     sync();
+#ifdef CTCFA_BT_PHASES
+    const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
+#endif
 
     if constexpr (CK) {
         // ---- phase A, checkpoint mode: all four waves --------------------------------------
@@ -1039,31 +1045,89 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         }
                     }
                 };
+                // Block jb is read from the slot in the step that walks block jb + 1 (the first
+                // block, jstart, is recomputed from global memory and never staged).
                 auto mine = [&](int jb) { return jb >= 0 && 1 + jb % 3 == wave; };
-                if (mine(jstart)) {
-                    issue(jstart);
-                    put(jstart);
+                if (mine(jstart - 1)) {
+                    issue(jstart - 1);
+                    put(jstart - 1);
                 }
-                if (mine(jstart - 1)) issue(jstart - 1);
                 if (mine(jstart - 2)) issue(jstart - 2);
-                for (int j = jstart; j >= 0; --j) {
-                    lds_barrier();  // A: block j is in the slot
+                if (mine(jstart - 3)) issue(jstart - 3);
+                for (int j = jstart; j >= 1; --j) {
+                    lds_barrier();  // A: block j - 1 is in the slot
                     lds_barrier();  // B: wave 0 has it in registers
-                    if (mine(j - 1)) put(j - 1);
-                    if (mine(j - 3)) issue(j - 3);
+                    if (mine(j - 2)) put(j - 2);
+                    if (mine(j - 4)) issue(j - 4);
                 }
             } else {
-                // ======== wave 0: recompute the block's decisions, then walk it ==================
-                int j = jstart;
-                int b0 = 31 - ((t_end - 1) & 31);
+                // ======== wave 0 =================================================================
+                // Step j: WALK block j (scalar: one v_readlane + four SALU operations per row) while
+                // the rows of block j - 1 are RECOMPUTED (vector) in the same instruction stream.
+                // The recompute has to start before the walk knows where the path leaves block j, so
+                // its lane 0 is the column where the path ENTERED block j; the path then enters block
+                // j - 1 at lane x = columns dropped in block j.  Row r of a block is wrong in lanes
+                // >= 63 - r and the path sits in lanes <= x + 31 - r: fine for x <= 31; x == 32 (a
+                // SWITCH in every row of block j) takes the slow path, as does the first block.
                 const uint32_t* seg_bits = bits + sd.bits_off;
-                // table row the block starts from = what the fill stored for block jb - 1
-                // (row 0: table[0,0] = 0, table[0,c>0] = -1e9), requested kDepth blocks ahead for
-                // the 192 columns the entry column can still lie in, re-based on arrival
+                const bool preamble = (p.flags & 2u) != 0;
+#ifdef CTCFA_BT_PRIO
+                __builtin_amdgcn_s_setprio(CTCFA_BT_PRIO);  // the walker is the kernel's critical chain
+#endif
+                auto cell = [&](float& prev, uint32_t& dec, float ee, float m) {
+                    const float pl = dpp_wave_shl1(prev);
+                    const float a = pl + ee;
+                    const float b = prev + m;
+                    const float nw = max3f(a, b, kProbMax);
+                    const float rsw = ee - (nw - pl);
+                    const float rst = m - (nw - prev);
+                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                    dec = __builtin_amdgcn_alignbit(dec, __float_as_uint(d), 31);
+                    prev = nw;
+                    asm volatile("" : "+v"(dec));  // pin the row (see the fill kernel): no sinking of 32 rows' residuals
+                };
+                // slow path: block jb with lane 0 = column `top`, operands straight from global memory
+                auto rows_slow = [&](int jb, int top) -> uint32_t {
+                    const int col = top - lane;
+                    const int c = col - shift;
+                    float prev;
+                    if (jb == 0) prev = c <= 0 ? 0.0f : kProbMax;                     // table row 0
+                    else prev = col >= 0 ? __uint_as_float(seg_bits[(int64_t)(jb - 1) * p.Cpad + col]) : 0.0f;
+                    const int lab = c <= 0 ? -1 : labs[c];
+                    float ee[kRows], lb[kRows];
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        int t = jb * kRows + 1 + i;
+                        t = t < T ? t : T - 1;
+                        lb[i] = seg_lpz[(int64_t)t * V + p.blank];
+                        ee[i] = seg_lpz[(int64_t)t * V + (lab < 0 ? 0 : lab)];
+                    }
+                    uint32_t dec = 0u;
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        const float e1 = lab < 0 ? -__builtin_inff() : ee[i];
+                        const float m = lab < 0 ? (preamble ? 0.0f : __builtin_fmaxf(lb[i], kProbMax))
+                                                : max3f(lb[i], ee[i], kProbMax);
+                        cell(prev, dec, e1, m);
+                    }
+                    return c <= 0 ? 0u : dec;  // start column and left of it: STAY
+                };
+
+                int j = jstart;
+                uint32_t W = rows_slow(jstart, pc);     // decision words of block j, lane i = column (top - i)
+                {
+                    const int b0 = 31 - ((t_end - 1) & 31);   // rows after t_end: not part of the path
+                    W &= ~((1u << b0) - 1u);
+                }
+                int x = 0;                              // lane of the column the path enters block j in
+                // Table row a block starts from = what the fill stored for the block before it,
+                // requested kDepth steps ahead for the 192 columns its lane 0 can still lie in and
+                // re-based on arrival.  (Branch-free and unconditional: a load under control flow
+                // makes the compiler wait for every outstanding load at the join; what must not be
+                // used is replaced on arrival.)
                 constexpr int kDepth = 4;
-                // (branch-free and unconditional: a load under control flow makes the compiler wait
-                // for every outstanding load at the join; what must not be used is replaced on arrival)
-                auto fetch = [&](int jb, int base, int part) -> uint32_t {
+                auto fetch = [&](int jb, int base, int part) -> uint32_t {  // start row of block jb
                     const int col = base - 64 * part - lane;
                     const int64_t idx = (jb >= 1 && col >= 0) ? (int64_t)(jb - 1) * p.Cpad + col : 0;
                     return seg_bits[idx];
@@ -1074,7 +1138,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 for (int u = 0; u < kDepth; ++u) {
                     pbase[u] = pc;
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - u, pc, q);
+                    for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - u, pc, q);
                 }
 #ifdef CTCFA_CK_STAMP
                 unsigned long long ck_s[4] = {0, 0, 0, 0};
@@ -1084,93 +1148,74 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
 #define CK_T(x)
 #define CK_ACC(i, a, b)
 #endif
-                while (j >= 0) {
+                while (j >= 1) {
 #pragma unroll
                     for (int u = 0; u < kDepth; ++u) {
-                        if (j < 0) break;
+                        if (j < 1) break;
                         CK_T(ck0);
-                        const int cstart = pc;
+                        // pc = column the path entered block j in = lane 0 of the recompute of block j - 1
                         const int src = (pbase[u] - pc) + lane;  // 0 .. 191
                         const uint32_t f0 = __shfl(pf[u][0], src & 63);
                         const uint32_t f1 = __shfl(pf[u][1], src & 63);
                         const uint32_t f2 = __shfl(pf[u][2], src & 63);
                         float prev = __uint_as_float((src < 64) ? f0 : (src < 128) ? f1 : f2);
-                        {
-                            const int col = pc - lane;
-                            if (j == 0) prev = col - shift <= 0 ? 0.0f : kProbMax;  // table row 0
-                            if (col < 0) prev = 0.0f;                                // left of the padded table
-                        }
+                        const int col = pc - lane;
+                        const int c = col - shift;                  // label column of this lane
+                        if (j == 1) prev = c <= 0 ? 0.0f : kProbMax;  // block 0 starts from table row 0
+                        if (col < 0) prev = 0.0f;                    // left of the padded table
                         pbase[u] = pc;
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - kDepth, pc, q);
-
-                        const int c = pc - lane - shift;           // label column of this lane
+                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - kDepth, pc, q);
                         const int lab = c <= 0 ? PB - 1 : labs[c];  // c < C: the path never sits right of C-1
                         const float2* erow = ering + lab;
                         float2 emr[kRows];
-                        lds_barrier();  // A: block j is in the slot
+                        lds_barrier();  // A: block j - 1 is in the slot
 #pragma unroll
                         for (int i = 0; i < kRows; ++i) emr[i] = erow[i * PB];
                         lds_barrier();  // B: the slot may be overwritten (waits for the reads above)
-                        uint32_t dec = 0u;
-#ifdef CTCFA_CK_STAMP
-                        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-                        asm volatile("" : "+v"(prev));
-#endif
                         CK_T(ck1);
+                        uint32_t dec = 0u, S = 0u;
+                        int pidx = 0;
 #pragma unroll
                         for (int i = 0; i < kRows; ++i) {
-                            const float ee = emr[i].x, m = emr[i].y;
-                            const float pl = dpp_wave_shl1(prev);
-                            const float a = pl + ee;
-                            const float b = prev + m;
-                            const float nw = max3f(a, b, kProbMax);
-                            const float rsw = ee - (nw - pl);
-                            const float rst = m - (nw - prev);
-                            const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
-                            dec = __builtin_amdgcn_alignbit(dec, __float_as_uint(d), 31);
-                            prev = nw;
+                            // walk, bit i of block j
+                            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
+                            const uint32_t bit = (w >> i) & 1u;
+                            S |= bit << i;
+                            pidx += (int)bit;
+                            // recompute, row i of block j - 1
+                            cell(prev, dec, emr[i].x, emr[i].y);
                         }
-                        uint32_t wl = c <= 0 ? 0u : dec;     // start column and left of it: STAY
-#ifdef CTCFA_CK_STAMP
-                        asm volatile("" : "+v"(wl));
-#endif
                         CK_T(ck2);
-                        uint32_t S = 0;
-                        int pidx = 0;
-                        int bb = b0;
-                        if (bb < kRows) {
-                            uint32_t tmp;
-                            asm volatile(
-                                "1:\n\t"
-                                "s_nop 3\n\t"
-                                "v_readlane_b32 %3, %4, %1\n\t"
-                                "s_lshr_b32 %3, %3, %2\n\t"
-                                "s_cmp_eq_u32 %3, 0\n\t"
-                                "s_cbranch_scc1 2f\n\t"
-                                "s_ff1_i32_b32 %3, %3\n\t"
-                                "s_add_i32 %3, %3, %2\n\t"
-                                "s_bitset1_b32 %0, %3\n\t"
-                                "s_add_i32 %2, %3, 1\n\t"
-                                "s_add_i32 %1, %1, 1\n\t"
-                                "s_cmp_lt_i32 %2, 32\n\t"
-                                "s_cbranch_scc1 1b\n\t"
-                                "2:"
-                                : "+s"(S), "+s"(pidx), "+s"(bb), "=&s"(tmp)
-                                : "v"(wl)
-                                : "scc");
-                        }
-                        pc -= pidx;
-                        if (lane == 0) rec[j] = make_int2(cstart, (int)S);
+                        if (lane == 0) rec[j] = make_int2(pc, (int)S);
+                        const int dropped = pidx;
+                        pc -= dropped;
                         --j;
-                        b0 = 0;
+                        if (dropped < kRows) {
+                            W = c <= 0 ? 0u : dec;
+                            x = dropped;
+                        } else {
+                            W = rows_slow(j, pc);
+                            x = 0;
+                        }
                         CK_T(ck3);
-                        CK_T(ck4);
                         CK_ACC(0, ck0, ck1);
                         CK_ACC(1, ck1, ck2);
                         CK_ACC(2, ck2, ck3);
-                        CK_ACC(3, ck3, ck4);
                     }
+                }
+                {   // block 0: nothing left to recompute
+                    uint32_t S = 0u;
+                    int pidx = 0;
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
+                        const uint32_t bit = (w >> i) & 1u;
+                        S |= bit << i;
+                        pidx += (int)bit;
+                    }
+                    if (lane == 0) rec[0] = make_int2(pc, (int)S);
+                    pc -= pidx;
                 }
 #ifdef CTCFA_CK_STAMP
                 if (lane == 0 && a.seg_start) {
@@ -1180,6 +1225,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
 #endif
             }
         }
+#ifdef CTCFA_BT_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (wave == 0 && lane == 0) {
             sh_misc[0] = t_end;
             sh_misc[1] = (pc - shift > 0);  // reached t == 0 in a label column: the package's IndexError
@@ -1294,6 +1342,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         }
     }
     sync();
+#ifdef CTCFA_BT_PHASES
+    const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+#endif
     const int t_end = sh_misc[0];
     if (sh_misc[1]) {
         fail(2);
@@ -1342,10 +1393,23 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     }
     if (!want_seg) return;
     sync();
+#ifdef CTCFA_BT_PHASES
+    const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- phase C: determine_utterance_segments ------------------------------------------------
     score_utterances<kThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,
                                seg_start, seg_end, seg_score, tid, tick);
+#ifdef CTCFA_BT_PHASES
+    sync();
+    if (tid == 0) {
+        const unsigned long long ph4 = __builtin_amdgcn_s_memtime();
+        seg_start[sd.utt_off + 0] = (double)(ph1 - ph0);
+        seg_start[sd.utt_off + 1] = (double)(ph2 - ph1);
+        seg_start[sd.utt_off + 2] = (double)(ph3 - ph2);
+        seg_start[sd.utt_off + 3] = (double)(ph4 - ph3);
+    }
+#endif
 }
 
 struct BlockSync {
@@ -1362,7 +1426,7 @@ struct WaveSync {  // one wave: program order + completed memory operations is a
 };
 
 template <int PB>  // 0: decision words from the fill; 33 / 65: checkpoint mode, V <= 32 / V <= 64
-__global__ void __launch_bounds__(kBtThreads)
+__global__ void __launch_bounds__(kBtThreads, 4)   // <= 128 VGPRs: two workgroups per CU beside the fill's
 backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_v[kBtThreads / 64];

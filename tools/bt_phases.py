@@ -1,5 +1,4 @@
-"""Diagnostic only: where the checkpoint-mode walk spends its cycles (build with -DCTCFA_CK_STAMP:
-python tools/make_variant.py base+-DCTCFA_CK_STAMP+-DCTCFA_DEV_VP32_ONLY; CTCFA_LIB=variants/... python tools/ck_stamps.py)."""
+"""Diagnostic only: cycles per phase of the backtrack kernel (build with -DCTCFA_BT_PHASES)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,12 +16,10 @@ t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.reshape(-1)).astype(dt
 d_lpz, d_lab, d_ub = t(lpz, np.float32), t(gt, np.int32), t(ub, np.int32)
 fol = torch.zeros(B * C, dtype=torch.int32, device=dev); cp = torch.zeros(B * T, dtype=torch.float32, device=dev)
 seg = torch.zeros(3, B * U, dtype=torch.float64, device=dev); te = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
-for _ in range(200):
+for _ in range(300):
     plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), fol.data_ptr(), cp.data_ptr(), None, seg[0].data_ptr(),
                     seg[1].data_ptr(), seg[2].data_ptr(), te.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 s = seg[0].cpu().numpy().reshape(B, U)
-nb = s[:, 4]
-print("blocks per segment (median) %d" % np.median(nb))
-for q, name in enumerate(("start row + emissions ready", "walk(j) + rows(j-1)", "hand-over", "-")):
-    print("  %-16s %6.0f ticks per block (median over segments)" % (name, np.median(s[:, q] / nb)))
+for q, name in enumerate(("end cell + staging", "walk", "per-frame outputs", "utterance scores")):
+    print("  %-20s %7.0f ticks (median over segments)" % (name, np.median(s[:, q])))
