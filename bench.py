@@ -43,10 +43,16 @@ def parse():
                     help="untimed passes of the same step before the warm-up steps (~0.25 s), so that the timed "
                          "region sees the card's sustained clocks and not the ramp from idle (0 = off)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of segment boundaries")
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="N > 1: segment boundaries of this many steps travel in one all-gather "
+                         "(fewer, larger collectives; every step's results are still gathered inside the timed region)")
     ap.add_argument("--timing-stride", type=int, default=0,
                     help="HIP-event bracket every n-th launch of the timed region (0 = 4, or 1 for short runs)")
     ap.add_argument("--serial", action="store_true",
                     help="one stream: fill then backtrack per step (default: backtrack of step k overlaps fill of k+1)")
+    ap.add_argument("--from-max-t", action="store_true",
+                    help="backtrack_from_max_t: every path ends in the last frame (the longest backtrack); "
+                         "the default recipe's paths end near frame 1950 of 3000")
     ap.add_argument("--no-check", action="store_true",
                     help="kernel-tuning only: skip the status/parity gate (ablated builds give wrong results)")
     return ap.parse_args()
@@ -87,6 +93,7 @@ def main():
     lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, seed0=rank * B)
     C = gt.shape[1]
     cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
+    cfg.backtrack_from_max_t = bool(args.from_max_t)
     eng = pkg._native.Engine(local_rank)
     plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane)
     info = plan.info
@@ -97,7 +104,6 @@ def main():
     def alloc_outputs():
         return dict(fol=torch.empty(B * C, dtype=torch.int32, device=dev),
                     cp=torch.empty(B * T, dtype=torch.float32, device=dev),
-                    seg=torch.empty(3, B * U, dtype=torch.float64, device=dev),
                     te=torch.empty(B, dtype=torch.int32, device=dev),
                     status=torch.empty(B, dtype=torch.int32, device=dev))
 
@@ -105,46 +111,58 @@ def main():
     # flight and the gather of step i-2 may still be reading while step i runs -> three sets
     outs = [alloc_outputs(), alloc_outputs(), alloc_outputs()]
     NSETS = len(outs)
-    gathered = torch.empty(world, 3, B * U, dtype=torch.float64, device=dev) if world > 1 else None
+    # Segment boundaries (start, end, score) -- what the job hands on -- go into group buffers:
+    # G consecutive steps fill one buffer, which then travels in ONE all-gather.  Three buffers:
+    # one being filled, one whose last steps are still in flight, one being gathered.
+    G = max(1, args.gather_every)
+    seg_ring = [torch.empty(G, 3, B * U, dtype=torch.float64, device=dev) for _ in range(3)]
+    gathered = torch.empty(world, G, 3, B * U, dtype=torch.float64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
     pipelined = not args.serial
     do_gather = world > 1 and not args.no_gather
     n_calls = [0]
+    n_gathered = [0]   # groups handed to the collective so far
 
-    def gather(o):
+    def seg_of(i):
+        return seg_ring[(i // G) % 3][i % G]
+
+    def gather(g):
         # the path's only exchange: gather the final segment boundaries (the role of
         # merge_aligned_files.py:17-25), on its own stream so it overlaps later steps
+        buf = seg_ring[g % 3]
         comm.wait_stream(stream)
         with torch.cuda.stream(comm):
             if rehearsal:   # gloo has no all_gather_into_tensor for device tensors
-                parts = [torch.empty_like(o["seg"]) for _ in range(world)]
-                dist.all_gather(parts, o["seg"])
+                parts = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(parts, buf)
             else:
-                dist.all_gather_into_tensor(gathered.view(-1), o["seg"].view(-1))
+                dist.all_gather_into_tensor(gathered.view(-1), buf.view(-1))
+        n_gathered[0] = g + 1
 
     def step():
         i = n_calls[0]
         n_calls[0] += 1
         o = outs[i % NSETS]
-        if do_gather:
-            stream.wait_stream(comm)   # the gather that last read this output set has finished
+        sg = seg_of(i)
+        if do_gather and i % G == 0 and i >= 3 * G:
+            stream.wait_stream(comm)   # the gather that last read this group buffer (group i/G - 3) has finished
         plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(),
-                        o["cp"].data_ptr(), None, o["seg"][0].data_ptr(), o["seg"][1].data_ptr(),
-                        o["seg"][2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(),
+                        o["cp"].data_ptr(), None, sg[0].data_ptr(), sg[1].data_ptr(),
+                        sg[2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(),
                         stream.cuda_stream, pipelined=pipelined)
         if do_gather:
-            if not pipelined:
-                gather(o)
-            elif i >= 2:
-                gather(outs[(i - 2) % NSETS])  # step i-2: complete on `stream` once this call has been enqueued
+            # serial: step i is complete on `stream` as soon as it is enqueued; pipelined: step i-2 is
+            done = i if not pipelined else i - 2
+            if done >= 0 and done % G == G - 1:
+                gather(done // G)
 
     def drain():
         if pipelined:
             plan.flush(stream.cuda_stream)
-            if do_gather:
-                for k in range(min(2, n_calls[0])):
-                    gather(outs[(n_calls[0] - 1 - k) % NSETS])
+        if do_gather:
+            for g in range(n_gathered[0], (n_calls[0] + G - 1) // G):   # groups not yet on their way (the last may be partial)
+                gather(g)
         if comm is not None:
             stream.wait_stream(comm)
 
@@ -173,6 +191,7 @@ def main():
     plan.set_timing(max(n_timed, 4))
     plan.set_timing_stride(stride)
     n_calls[0] = 0
+    n_gathered[0] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -188,13 +207,13 @@ def main():
 
     # ---- parity gate on the timed inputs (a sample; the full sweep is tests/ -m gpu) -------
     last = outs[(args.steps - 1) % NSETS]
-    d_status, d_fol, d_seg, d_cp = last["status"], last["fol"], last["seg"], last["cp"]
+    d_status, d_fol, d_seg, d_cp = last["status"], last["fol"], seg_of(args.steps - 1), last["cp"]
     status = d_status.cpu().numpy()
     assert args.no_check or (status == 0).all(), "non-OK status in the benchmark batch"
     parity = None
     if rank == 0 and not args.no_check:
         from oracle import oracle_c
-        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
+        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION, backtrack_from_max_t=int(args.from_max_t))
         fol = d_fol.cpu().numpy().reshape(B, C)
         seg = d_seg.cpu().numpy().reshape(3, B, U)
         cp = d_cp.cpu().numpy().reshape(B, T)
@@ -286,6 +305,7 @@ def main():
                        "segments_per_gpu": B, "frames": T, "vocab": V, "label_columns": C,
                        "cols_per_lane": info["cols_per_lane"], "waves_per_segment": info["waves_per_seg"],
                        "parallelism": f"segment-sharded x{world}", "parity": parity,
+                       "gather": (f"RCCL all-gather of (start, end, score), one per {G} steps" if do_gather else None),
                        "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
             "roofline": {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -1126,10 +1126,13 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 // re-based on arrival.  (Branch-free and unconditional: a load under control flow
                 // makes the compiler wait for every outstanding load at the join; what must not be
                 // used is replaced on arrival.)
-                constexpr int kDepth = 4;
+#ifndef CTCFA_CK_DEPTH
+#define CTCFA_CK_DEPTH 4
+#endif
+                constexpr int kDepth = CTCFA_CK_DEPTH;
                 auto fetch = [&](int jb, int base, int part) -> uint32_t {  // start row of block jb
                     const int col = base - 64 * part - lane;
-                    const int64_t idx = (jb >= 1 && col >= 0) ? (int64_t)(jb - 1) * p.Cpad + col : 0;
+                    const uint32_t idx = (jb >= 1 && col >= 0) ? (uint32_t)((jb - 1) * p.Cpad + col) : 0u;  // < 2^31: one segment's words
                     return seg_bits[idx];
                 };
                 uint32_t pf[kDepth][3];
@@ -1180,9 +1183,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         for (int i = 0; i < kRows; ++i) {
                             // walk, bit i of block j
                             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
-                            const uint32_t bit = (w >> i) & 1u;
-                            S |= bit << i;
-                            pidx += (int)bit;
+                            S |= w & (1u << i);
+                            pidx += (int)((w >> i) & 1u);
+                            asm volatile("" : "+s"(S));  // (else the 32 bits are kept apart and merged at the end)
                             // recompute, row i of block j - 1
                             cell(prev, dec, emr[i].x, emr[i].y);
                         }
@@ -1210,9 +1213,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
 #pragma unroll
                     for (int i = 0; i < kRows; ++i) {
                         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
-                        const uint32_t bit = (w >> i) & 1u;
-                        S |= bit << i;
-                        pidx += (int)bit;
+                        S |= w & (1u << i);
+                        pidx += (int)((w >> i) & 1u);
+                        asm volatile("" : "+s"(S));
                     }
                     if (lane == 0) rec[0] = make_int2(pc, (int)S);
                     pc -= pidx;
