@@ -571,7 +571,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                 if (pl->segs[b].prestatus == CTCFA_ST_OK) Cbt = std::max(Cbt, (int)C[b]);
             pl->lab_bytes = (Cbt * 4 + 15) / 16 * 16;
             const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8;
-            pl->lds_bt = pl->rec_bytes + pl->lab_bytes + std::max(Tbt * 4, ring);
+            pl->lds_bt = pl->rec_bytes + pl->lab_bytes + std::max(Tbt * 4, ring + 256);  // + 64 decision words, recompute wave -> walker
         }
     }
     if (pl->lds_bt > eng->lds_limit) {

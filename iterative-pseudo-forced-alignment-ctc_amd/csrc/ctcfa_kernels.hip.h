@@ -943,9 +943,6 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         return;
     }
 
-#ifdef CTCFA_BT_PHASES
-    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
-#endif
     // ---- phase 0: first maximum of the last column (lastMax/lastArgMax of the fill) --------
     {
         const float* lc = lastcol + sd.frm_off;
@@ -981,9 +978,6 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         for (int c = tid; c < C; c += kThreads) labs[c] = seg_lab[c];
     }
     sync();
-#ifdef CTCFA_BT_PHASES
-    const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
-#endif
 
     if constexpr (CK) {
         // ---- phase A, checkpoint mode: all four waves --------------------------------------
@@ -1005,31 +999,48 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         int pc = C - 1 + shift;
         if (t_end >= 1) {
             const int jstart = (t_end - 1) >> 5;
-            if (wave != 0) {
-                // ======== producers: block jb is staged by wave 1 + jb % 3; its loads are issued
-                // three steps before the block is walked and written to the ring one step before.
-                // lane v < V stages vocabulary entry v of every row; lane V (if there is one) the
-                // start column's pseudo entry.  Everything sits under ONE lane mask per block: a
-                // put() has to fit inside the step of the block that is being walked.
-                float e[kRows];
+            // Roles: wave 0 recomputes decision words, wave 1 walks them, waves 2-3 stage emissions.
+            // Step j (j = jstart .. 0): the walker walks block j while wave 0 recomputes block j - 1,
+            // which it has to start before the walk knows where the path leaves block j: its lane 0
+            // is the column where the path ENTERED block j (pcj), and the path then enters block
+            // j - 1 at lane x = columns dropped in block j.  Row r of a recomputed block is wrong in
+            // lanes >= 63 - r (their left neighbours lie outside the wave) and the path sits in lanes
+            // <= x + 31 - r: fine for x <= 31.  x == 32 (a SWITCH in every row of block j) raises
+            // sh_misc[3] and block j - 1 is recomputed from its exact entry column at the start of
+            // the next step (slow path, as for the first block).
+            // Two LDS-only barriers per step: A (emission slot filled, decision words of block j and
+            // its entry column published) and B (slot and word buffer read, both may be overwritten);
+            // a third one, F, in the steps that take the slow path.
+            uint32_t* wbuf = reinterpret_cast<uint32_t*>(ering + kRows * PB);  // 64 words right after the emission slot
+            if (wave >= 2) {
+                // ======== producers: wave 2 stages rows 0-15 of every block, wave 3 rows 16-31.  Block
+                // jb is read in step jb + 1; its loads are issued in step jb + 4 and written to the
+                // slot in step jb + 2 (two register sets, by block parity).  Lane v < V stages
+                // vocabulary entry v of its rows, lane V (if there is one) the start column's pseudo
+                // entry; everything under ONE lane mask per block: put + issue have to fit in a step.
+                __builtin_amdgcn_s_setprio(1);
+                constexpr int kHalf = kRows / 2;
+                const int r0 = (wave - 2) * kHalf;
+                float e0[kHalf], e1[kHalf];
                 const bool preamble = (p.flags & 2u) != 0;
                 const bool is_pseudo = lane == V;             // no such lane when V == 64
                 const int woff = is_pseudo ? PB - 1 : lane;
-                auto issue = [&](int jb) {
-                    if (lane < V) {
+                auto issue = [&](int jb, float (&e)[kHalf]) {
+                    if (jb >= 0 && lane < V) {
 #pragma unroll
-                        for (int r = 0; r < kRows; ++r) {
-                            int t = jb * kRows + 1 + r;
+                        for (int r = 0; r < kHalf; ++r) {
+                            int t = jb * kRows + 1 + r0 + r;
                             t = t < T ? t : T - 1;   // rows past the end: decisions nobody reads
                             e[r] = seg_lpz[(int64_t)t * V + lane];
                         }
                     }
                 };
-                auto put = [&](int jb) {
-                    float2* slot = ering + woff;
+                auto put = [&](int jb, const float (&e)[kHalf]) {
+                    if (jb < 0) return;
+                    float2* slot = ering + r0 * PB + woff;
                     if (lane <= V) {
 #pragma unroll
-                        for (int r = 0; r < kRows; ++r) {
+                        for (int r = 0; r < kHalf; ++r) {
                             const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
                             const float m = max3f(lb, e[r], kProbMax);
                             const float pm = preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax);  // start column's stay step
@@ -1038,42 +1049,105 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                     }
                     if (V == 64 && lane == 0) {
 #pragma unroll
-                        for (int r = 0; r < kRows; ++r) {
+                        for (int r = 0; r < kHalf; ++r) {
                             const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
-                            ering[r * PB + PB - 1] = make_float2(-__builtin_inff(),
-                                                                 preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                            ering[(r0 + r) * PB + PB - 1] = make_float2(-__builtin_inff(),
+                                                                        preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         }
                     }
                 };
-                // Block jb is read from the slot in the step that walks block jb + 1 (the first
-                // block, jstart, is recomputed from global memory and never staged).
-                auto mine = [&](int jb) { return jb >= 0 && 1 + jb % 3 == wave; };
-                if (mine(jstart - 1)) {
-                    issue(jstart - 1);
-                    put(jstart - 1);
+                // V == 32 (the common case): a lane moves four consecutive entries of a row with one
+                // dwordx4, eight lanes share a row, eight rows per pass -- two passes per half block.
+                const int vq = lane & 7, vr = lane >> 3;
+                float4 q0[2], q1[2];
+                auto issue4 = [&](int jb, float4 (&e)[2]) {
+                    if (jb < 0) return;
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        int t = jb * kRows + 1 + r0 + ps * 8 + vr;
+                        t = t < T ? t : T - 1;
+                        e[ps] = *reinterpret_cast<const float4*>(seg_lpz + (int64_t)t * 32 + 4 * vq);
+                    }
+                };
+                auto put4 = [&](int jb, const float4 (&e)[2]) {
+                    if (jb < 0) return;
+                    const int bq = p.blank >> 2, bc = p.blank & 3;
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const float4 v = e[ps];
+                        const float own = bc == 0 ? v.x : bc == 1 ? v.y : bc == 2 ? v.z : v.w;
+                        const float lb = __shfl(own, (lane & ~7) | bq);     // the row's blank entry
+                        float2* row = ering + (r0 + ps * 8 + vr) * PB;
+                        row[4 * vq + 0] = make_float2(v.x, max3f(lb, v.x, kProbMax));
+                        row[4 * vq + 1] = make_float2(v.y, max3f(lb, v.y, kProbMax));
+                        row[4 * vq + 2] = make_float2(v.z, max3f(lb, v.z, kProbMax));
+                        row[4 * vq + 3] = make_float2(v.w, max3f(lb, v.w, kProbMax));
+                        if (vq == 0)  // start column: e = -inf, m = its stay step
+                            row[PB - 1] = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                    }
+                };
+                // set 0: blocks of jstart's parity, set 1: the others
+                auto run = [&](auto&& issue_f, auto&& put_f, auto& s0, auto& s1) {
+                    issue_f(jstart - 1, s1);
+                    put_f(jstart - 1, s1);
+                    issue_f(jstart - 3, s1);
+                    issue_f(jstart - 2, s0);
+                    auto step = [&](int j, auto& e) {
+                        lds_barrier();                              // A
+                        const int slow = sh_misc[3];
+                        lds_barrier();                              // B
+                        if (slow) lds_barrier();                    // F
+                        put_f(j - 2, e);
+                        issue_f(j - 4, e);
+                    };
+                    for (int j = jstart; j >= 0; j -= 2) {
+                        step(j, s0);
+                        if (j >= 1) step(j - 1, s1);
+                    }
+                };
+                if (PB == 33 && V == 32) run(issue4, put4, q0, q1);
+                else run(issue, put, e0, e1);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (wave == 1) {
+                // ======== walker: one v_readlane + four scalar operations per row ====================
+                __builtin_amdgcn_s_setprio(3);
+                int x = 0;
+                for (int j = jstart; j >= 0; --j) {
+                    lds_barrier();                              // A
+                    const int slow = sh_misc[3];
+                    if (slow) {
+                        lds_barrier();                          // F: block j recomputed from its exact entry column
+                        x = 0;
+                    }
+                    const uint32_t W = wbuf[lane];
+                    const int pcj = sh_misc[2];
+                    lds_barrier();                              // B (waits for the two reads above)
+                    uint32_t S = 0u;
+                    int pidx = 0;
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
+                        S |= w & (1u << i);
+                        pidx += (int)((w >> i) & 1u);
+                    }
+                    if (lane == 0) {
+                        rec[j] = make_int2(pcj, (int)S);
+                        sh_misc[2] = pcj - pidx;                    // entry column of block j - 1
+                        sh_misc[3] = (pidx >= kRows && j >= 1) ? 1 : 0;
+                    }
+                    x = pidx;
+                    pc = pcj - pidx;
                 }
-                if (mine(jstart - 2)) issue(jstart - 2);
-                if (mine(jstart - 3)) issue(jstart - 3);
-                for (int j = jstart; j >= 1; --j) {
-                    lds_barrier();  // A: block j - 1 is in the slot
-                    lds_barrier();  // B: wave 0 has it in registers
-                    if (mine(j - 2)) put(j - 2);
-                    if (mine(j - 4)) issue(j - 4);
+                __builtin_amdgcn_s_setprio(0);
+                if (lane == 0) {
+                    sh_misc[0] = t_end;
+                    sh_misc[1] = (pc - shift > 0);  // reached t == 0 in a label column: the package's IndexError
                 }
             } else {
-                // ======== wave 0 =================================================================
-                // Step j: WALK block j (scalar: one v_readlane + four SALU operations per row) while
-                // the rows of block j - 1 are RECOMPUTED (vector) in the same instruction stream.
-                // The recompute has to start before the walk knows where the path leaves block j, so
-                // its lane 0 is the column where the path ENTERED block j; the path then enters block
-                // j - 1 at lane x = columns dropped in block j.  Row r of a block is wrong in lanes
-                // >= 63 - r and the path sits in lanes <= x + 31 - r: fine for x <= 31; x == 32 (a
-                // SWITCH in every row of block j) takes the slow path, as does the first block.
+                // ======== wave 0: recompute =========================================================
+                __builtin_amdgcn_s_setprio(3);
                 const uint32_t* seg_bits = bits + sd.bits_off;
                 const bool preamble = (p.flags & 2u) != 0;
-#ifdef CTCFA_BT_PRIO
-                __builtin_amdgcn_s_setprio(CTCFA_BT_PRIO);  // the walker is the kernel's critical chain
-#endif
                 auto cell = [&](float& prev, uint32_t& dec, float ee, float m) {
                     const float pl = dpp_wave_shl1(prev);
                     const float a = pl + ee;
@@ -1113,21 +1187,21 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                     }
                     return c <= 0 ? 0u : dec;  // start column and left of it: STAY
                 };
-
-                int j = jstart;
-                uint32_t W = rows_slow(jstart, pc);     // decision words of block j, lane i = column (top - i)
-                {
-                    const int b0 = 31 - ((t_end - 1) & 31);   // rows after t_end: not part of the path
-                    W &= ~((1u << b0) - 1u);
+                {   // first block: exact entry column, rows after t_end are not part of the path
+                    const int b0 = 31 - ((t_end - 1) & 31);
+                    wbuf[lane] = rows_slow(jstart, pc) & ~((1u << b0) - 1u);
+                    if (lane == 0) {
+                        sh_misc[2] = pc;
+                        sh_misc[3] = 0;
+                    }
                 }
-                int x = 0;                              // lane of the column the path enters block j in
                 // Table row a block starts from = what the fill stored for the block before it,
                 // requested kDepth steps ahead for the 192 columns its lane 0 can still lie in and
                 // re-based on arrival.  (Branch-free and unconditional: a load under control flow
                 // makes the compiler wait for every outstanding load at the join; what must not be
                 // used is replaced on arrival.)
 #ifndef CTCFA_CK_DEPTH
-#define CTCFA_CK_DEPTH 4
+#define CTCFA_CK_DEPTH 2
 #endif
                 constexpr int kDepth = CTCFA_CK_DEPTH;
                 auto fetch = [&](int jb, int base, int part) -> uint32_t {  // start row of block jb
@@ -1137,107 +1211,56 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 };
                 uint32_t pf[kDepth][3];
                 int pbase[kDepth];
+                int j = jstart;
 #pragma unroll
                 for (int u = 0; u < kDepth; ++u) {
                     pbase[u] = pc;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - u, pc, q);
                 }
-#ifdef CTCFA_CK_STAMP
-                unsigned long long ck_s[4] = {0, 0, 0, 0};
-#define CK_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
-#define CK_ACC(i, a, b) ck_s[i] += (b) - (a)
-#else
-#define CK_T(x)
-#define CK_ACC(i, a, b)
-#endif
-                while (j >= 1) {
+                while (j >= 0) {
 #pragma unroll
                     for (int u = 0; u < kDepth; ++u) {
-                        if (j < 1) break;
-                        CK_T(ck0);
-                        // pc = column the path entered block j in = lane 0 of the recompute of block j - 1
-                        const int src = (pbase[u] - pc) + lane;  // 0 .. 191
+                        if (j < 0) break;
+                        lds_barrier();                          // A
+                        if (sh_misc[3]) {                       // block j's words were computed for a window the path left
+                            wbuf[lane] = rows_slow(j, sh_misc[2]);
+                            lds_barrier();                      // F
+                        }
+                        const int pcj = sh_misc[2];             // entry column of block j = lane 0 of block j - 1
+                        const int src = (pbase[u] - pcj) + lane;  // 0 .. 191
                         const uint32_t f0 = __shfl(pf[u][0], src & 63);
                         const uint32_t f1 = __shfl(pf[u][1], src & 63);
                         const uint32_t f2 = __shfl(pf[u][2], src & 63);
                         float prev = __uint_as_float((src < 64) ? f0 : (src < 128) ? f1 : f2);
-                        const int col = pc - lane;
+                        const int col = pcj - lane;
                         const int c = col - shift;                  // label column of this lane
                         if (j == 1) prev = c <= 0 ? 0.0f : kProbMax;  // block 0 starts from table row 0
                         if (col < 0) prev = 0.0f;                    // left of the padded table
-                        pbase[u] = pc;
+                        pbase[u] = pcj;
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - kDepth, pc, q);
-                        const int lab = c <= 0 ? PB - 1 : labs[c];  // c < C: the path never sits right of C-1
+                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - kDepth, pcj, q);
+                        const int lab = c <= 0 ? PB - 1 : labs[c < C ? c : 0];  // c < C: the path never sits right of C-1
                         const float2* erow = ering + lab;
                         float2 emr[kRows];
-                        lds_barrier();  // A: block j - 1 is in the slot
 #pragma unroll
                         for (int i = 0; i < kRows; ++i) emr[i] = erow[i * PB];
-                        lds_barrier();  // B: the slot may be overwritten (waits for the reads above)
-                        CK_T(ck1);
-                        uint32_t dec = 0u, S = 0u;
-                        int pidx = 0;
+                        lds_barrier();                          // B (waits for the reads above)
+                        if (j >= 1) {
+                            uint32_t dec = 0u;
 #pragma unroll
-                        for (int i = 0; i < kRows; ++i) {
-                            // walk, bit i of block j
-                            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
-                            S |= w & (1u << i);
-                            pidx += (int)((w >> i) & 1u);
-                            asm volatile("" : "+s"(S));  // (else the 32 bits are kept apart and merged at the end)
-                            // recompute, row i of block j - 1
-                            cell(prev, dec, emr[i].x, emr[i].y);
+                            for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y);
+                            wbuf[lane] = c <= 0 ? 0u : dec;
                         }
-                        CK_T(ck2);
-                        if (lane == 0) rec[j] = make_int2(pc, (int)S);
-                        const int dropped = pidx;
-                        pc -= dropped;
                         --j;
-                        if (dropped < kRows) {
-                            W = c <= 0 ? 0u : dec;
-                            x = dropped;
-                        } else {
-                            W = rows_slow(j, pc);
-                            x = 0;
-                        }
-                        CK_T(ck3);
-                        CK_ACC(0, ck0, ck1);
-                        CK_ACC(1, ck1, ck2);
-                        CK_ACC(2, ck2, ck3);
                     }
                 }
-                {   // block 0: nothing left to recompute
-                    uint32_t S = 0u;
-                    int pidx = 0;
-#pragma unroll
-                    for (int i = 0; i < kRows; ++i) {
-                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
-                        S |= w & (1u << i);
-                        pidx += (int)((w >> i) & 1u);
-                        asm volatile("" : "+s"(S));
-                    }
-                    if (lane == 0) rec[0] = make_int2(pc, (int)S);
-                    pc -= pidx;
-                }
-#ifdef CTCFA_CK_STAMP
-                if (lane == 0 && a.seg_start) {
-                    for (int q = 0; q < 4; ++q) a.seg_start[sd.utt_off + q] = (double)ck_s[q];
-                    a.seg_start[sd.utt_off + 4] = (double)(jstart + 1);
-                }
-#endif
+                __builtin_amdgcn_s_setprio(0);
             }
-        }
-#ifdef CTCFA_BT_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (wave == 0 && lane == 0) {
+        } else if (wave == 1 && lane == 0) {
             sh_misc[0] = t_end;
-            sh_misc[1] = (pc - shift > 0);  // reached t == 0 in a label column: the package's IndexError
+            sh_misc[1] = (pc - shift > 0);
         }
-#ifdef CTCFA_CK_STAMP
-        return;
-#endif
     } else
     // ---- phase A (wave 0): the walk, one scalar step per run of STAYs ----------------------
     if (wave == 0) {
@@ -1345,9 +1368,6 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         }
     }
     sync();
-#ifdef CTCFA_BT_PHASES
-    const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
-#endif
     const int t_end = sh_misc[0];
     if (sh_misc[1]) {
         fail(2);
@@ -1396,23 +1416,10 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     }
     if (!want_seg) return;
     sync();
-#ifdef CTCFA_BT_PHASES
-    const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
-#endif
 
     // ---- phase C: determine_utterance_segments ------------------------------------------------
     score_utterances<kThreads>(sd, p.L, p.dur, utt_begin + sd.utt_off + sd.seg_index, fol, cps, T, C, U,
                                seg_start, seg_end, seg_score, tid, tick);
-#ifdef CTCFA_BT_PHASES
-    sync();
-    if (tid == 0) {
-        const unsigned long long ph4 = __builtin_amdgcn_s_memtime();
-        seg_start[sd.utt_off + 0] = (double)(ph1 - ph0);
-        seg_start[sd.utt_off + 1] = (double)(ph2 - ph1);
-        seg_start[sd.utt_off + 2] = (double)(ph3 - ph2);
-        seg_start[sd.utt_off + 3] = (double)(ph4 - ph3);
-    }
-#endif
 }
 
 struct BlockSync {
@@ -1434,7 +1441,7 @@ backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_v[kBtThreads / 64];
     __shared__ int red_t[kBtThreads / 64];
-    __shared__ int sh_misc[2];  // [0] t_end, [1] bad
+    __shared__ int sh_misc[4];  // [0] t_end, [1] bad; checkpoint mode: [2] entry column of the block to walk, [3] slow-path flag
     const SegDesc sd = a.segs[blockIdx.x];
     backtrack_body<kBtThreads, PB>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
 }
