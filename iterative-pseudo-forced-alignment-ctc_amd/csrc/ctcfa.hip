@@ -236,7 +236,7 @@ int vgprs_of(int K) {  // compiled register counts, rounded up (allocation granu
     }
 }
 
-bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k, bool allow_mixed,
+bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k, bool allow_mixed, bool ckpt,
                 ShapeChoice* out) {
     double best_cost = -1.0;
     ShapeChoice best{0, 0, false};
@@ -246,7 +246,8 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
     // model says (V = 76: K=5 in one round 467 us, K=2 in two rounds 757 us).  First look only at
     // shapes that hold the whole batch at once; fall back to everything if there is none.
     bool single_round_only = VP > 64;
-    auto instr = [](int K) { return 9.5 * K + 7.0; };
+    // per row of a K-column tile: 9.5 VALU per cell with the decision math, 3.5 in checkpoint mode
+    auto instr = [ckpt](int K) { return (ckpt ? 3.5 : 9.5) * K + 7.0; };
     auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
         const int lds = lds_bytes_fill(stages, VP);
         if (lds > lds_limit) return;
@@ -440,6 +441,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
            : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
     pl->have_utt = (U != nullptr);
+    // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
+    // of decision words and the backtrack recomputes the decisions along the path.
+    // CTCFA_DECISION_BITS=1 forces the decision-word mode the wider vocabularies use (tests).
+    pl->ckpt = !gather && pl->VP <= 64 && !std::getenv("CTCFA_DECISION_BITS");
 
     int Cmax = 2, Tmax = 1;
     for (int b = 0; b < batch; ++b) {
@@ -459,7 +464,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128: at most 961 label columns per segment");
         }
         shape = {1, W, false};
-    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"), &shape)) {
+    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"),
+                           pl->ckpt, &shape)) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }
@@ -473,7 +479,6 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         pl->roles.nwaves = pl->W;
         pl->roles.wave[pl->W] = {ctcfa::kRoleIdle, 0, 0};
     }
-    pl->ckpt = !gather && pl->VP <= 64 && !std::getenv("CTCFA_DECISION_BITS");
     pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP, pl->ckpt);
     if (!pl->fill_fn) {
         delete pl;
