@@ -50,6 +50,9 @@ def parse():
                     help="HIP-event bracket every n-th launch of the timed region (0 = 4, or 1 for short runs)")
     ap.add_argument("--serial", action="store_true",
                     help="one stream: fill then backtrack per step (default: backtrack of step k overlaps fill of k+1)")
+    ap.add_argument("--from-max-t", action="store_true",
+                    help="backtrack_from_max_t: every path ends in the last frame (the longest backtrack); "
+                         "the default recipe's paths end near frame 1950 of 3000")
     ap.add_argument("--no-check", action="store_true",
                     help="kernel-tuning only: skip the status/parity gate (ablated builds give wrong results)")
     return ap.parse_args()
@@ -90,6 +93,7 @@ def main():
     lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, seed0=rank * B)
     C = gt.shape[1]
     cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
+    cfg.backtrack_from_max_t = bool(args.from_max_t)
     eng = pkg._native.Engine(local_rank)
     plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane)
     info = plan.info
@@ -209,7 +213,7 @@ def main():
     parity = None
     if rank == 0 and not args.no_check:
         from oracle import oracle_c
-        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
+        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION, backtrack_from_max_t=int(args.from_max_t))
         fol = d_fol.cpu().numpy().reshape(B, C)
         seg = d_seg.cpu().numpy().reshape(3, B, U)
         cp = d_cp.cpu().numpy().reshape(B, T)

@@ -43,7 +43,8 @@ struct ctcfa_plan {
     ctcfa_engine* eng = nullptr;
     ctcfa_params prm{};
     int B = 0, V = 0, K = 0, W = 0, VP = 0;
-    int lds_fill = 0, lds_bt = 0, rec_bytes = 0, nblk_max = 0;
+    int lds_fill = 0, lds_bt = 0, rec_bytes = 0, lab_bytes = 0, nblk_max = 0;
+    bool ckpt = false;  // fill stores table rows, the backtrack recomputes its decisions (V <= 64)
     bool have_utt = false;
     std::vector<SegDesc> segs;
     int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
@@ -100,58 +101,54 @@ int set_err(ctcfa_engine* e, int code, const std::string& msg) {
 using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
                         const ctcfa::FillRoles*);
 
-template <int VP>
+template <int VP, bool CK>
 FillFn fill_for_k(int K) {
     switch (K) {
-        case 1: return ctcfa::fill_kernel<1, 1, VP>;
-        case 2: return ctcfa::fill_kernel<2, 2, VP>;
-        case 3: return ctcfa::fill_kernel<3, 3, VP>;
-        case 4: return ctcfa::fill_kernel<4, 4, VP>;
-        case 5: return ctcfa::fill_kernel<5, 5, VP>;
-        case 6: return ctcfa::fill_kernel<6, 6, VP>;
-        case 8: return ctcfa::fill_kernel<8, 8, VP>;
-        case 10: return ctcfa::fill_kernel<10, 10, VP>;
-        case 12: return ctcfa::fill_kernel<12, 12, VP>;
-        case 16: return ctcfa::fill_kernel<16, 16, VP>;
+        case 1: return ctcfa::fill_kernel<1, 1, VP, CK>;
+        case 2: return ctcfa::fill_kernel<2, 2, VP, CK>;
+        case 3: return ctcfa::fill_kernel<3, 3, VP, CK>;
+        case 4: return ctcfa::fill_kernel<4, 4, VP, CK>;
+        case 5: return ctcfa::fill_kernel<5, 5, VP, CK>;
+        case 6: return ctcfa::fill_kernel<6, 6, VP, CK>;
+        case 8: return ctcfa::fill_kernel<8, 8, VP, CK>;
+        case 10: return ctcfa::fill_kernel<10, 10, VP, CK>;
+        case 12: return ctcfa::fill_kernel<12, 12, VP, CK>;
+        case 16: return ctcfa::fill_kernel<16, 16, VP, CK>;
+        default: return nullptr;
+    }
+}
+
+template <int VP, bool CK>
+FillFn fill_mixed(int KH) {
+    switch (KH) {
+        case 2: return ctcfa::fill_kernel<2, 1, VP, CK>;
+        case 4: return ctcfa::fill_kernel<4, 2, VP, CK>;
         default: return nullptr;
     }
 }
 
 template <int VP>
-FillFn fill_mixed(int KH) {
-    switch (KH) {
-        case 2: return ctcfa::fill_kernel<2, 1, VP>;
-        case 4: return ctcfa::fill_kernel<4, 2, VP>;
-        default: return nullptr;
+FillFn fill_any(int KH, int KL, bool ck) {
+    if constexpr (VP <= 64) {
+        if (ck) return KL == KH ? fill_for_k<VP, true>(KH) : fill_mixed<VP, true>(KH);
     }
+    return KL == KH ? fill_for_k<VP, false>(KH) : fill_mixed<VP, false>(KH);
 }
 
 // KL == KH: uniform tiles; KL == KH / 2: the mixed 8-wave shape
-FillFn select_fill(int KH, int KL, int VP) {
-    if (KL == KH) {
-        switch (VP) {
-            case 32: return fill_for_k<32>(KH);
-            case 40: return fill_for_k<40>(KH);
-            case 48: return fill_for_k<48>(KH);
-            case 56: return fill_for_k<56>(KH);
-            case 64: return fill_for_k<64>(KH);
-            case 80: return fill_for_k<80>(KH);
-            case 96: return fill_for_k<96>(KH);
-            case 112: return fill_for_k<112>(KH);
-            case 128: return fill_for_k<128>(KH);
-            default: return nullptr;
-        }
-    }
+FillFn select_fill(int KH, int KL, int VP, bool ck) {
     switch (VP) {
-        case 32: return fill_mixed<32>(KH);
-        case 40: return fill_mixed<40>(KH);
-        case 48: return fill_mixed<48>(KH);
-        case 56: return fill_mixed<56>(KH);
-        case 64: return fill_mixed<64>(KH);
-        case 80: return fill_mixed<80>(KH);
-        case 96: return fill_mixed<96>(KH);
-        case 112: return fill_mixed<112>(KH);
-        case 128: return fill_mixed<128>(KH);
+        case 32: return fill_any<32>(KH, KL, ck);
+#ifndef CTCFA_DEV_VP32_ONLY  // tuning builds (tools/make_variant.py): one pitch compiles in a fifth of the time
+        case 40: return fill_any<40>(KH, KL, ck);
+        case 48: return fill_any<48>(KH, KL, ck);
+        case 56: return fill_any<56>(KH, KL, ck);
+        case 64: return fill_any<64>(KH, KL, ck);
+        case 80: return fill_any<80>(KH, KL, ck);
+        case 96: return fill_any<96>(KH, KL, ck);
+        case 112: return fill_any<112>(KH, KL, ck);
+        case 128: return fill_any<128>(KH, KL, ck);
+#endif
         default: return nullptr;
     }
 }
@@ -239,7 +236,7 @@ int vgprs_of(int K) {  // compiled register counts, rounded up (allocation granu
     }
 }
 
-bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k, bool allow_mixed,
+bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k, bool allow_mixed, bool ckpt,
                 ShapeChoice* out) {
     double best_cost = -1.0;
     ShapeChoice best{0, 0, false};
@@ -249,7 +246,8 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
     // model says (V = 76: K=5 in one round 467 us, K=2 in two rounds 757 us).  First look only at
     // shapes that hold the whole batch at once; fall back to everything if there is none.
     bool single_round_only = VP > 64;
-    auto instr = [](int K) { return 9.5 * K + 7.0; };
+    // per row of a K-column tile: 9.5 VALU per cell with the decision math, 3.5 in checkpoint mode
+    auto instr = [ckpt](int K) { return (ckpt ? 3.5 : 9.5) * K + 7.0; };
     auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
         const int lds = lds_bytes_fill(stages, VP);
         if (lds > lds_limit) return;
@@ -443,6 +441,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
            : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
     pl->have_utt = (U != nullptr);
+    // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
+    // of decision words and the backtrack recomputes the decisions along the path.
+    // CTCFA_DECISION_BITS=1 forces the decision-word mode the wider vocabularies use (tests).
+    pl->ckpt = !gather && pl->VP <= 64 && !std::getenv("CTCFA_DECISION_BITS");
 
     int Cmax = 2, Tmax = 1;
     for (int b = 0; b < batch; ++b) {
@@ -462,7 +464,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128: at most 961 label columns per segment");
         }
         shape = {1, W, false};
-    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"), &shape)) {
+    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"),
+                           pl->ckpt, &shape)) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }
@@ -476,7 +479,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         pl->roles.nwaves = pl->W;
         pl->roles.wave[pl->W] = {ctcfa::kRoleIdle, 0, 0};
     }
-    pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP);
+    pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP, pl->ckpt);
     if (!pl->fill_fn) {
         delete pl;
         return set_err(eng, CTCFA_ERR_INVALID, "unsupported cols_per_lane");
@@ -567,6 +570,14 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         for (int b = 0; b < batch; ++b)
             if (pl->segs[b].prestatus == CTCFA_ST_OK) Tbt = std::max(Tbt, (int)T[b]);
         pl->lds_bt = pl->rec_bytes + Tbt * 4;
+        if (pl->ckpt) {  // + label copy; the emission ring of the walk shares its LDS with char_probs
+            int Cbt = 1;
+            for (int b = 0; b < batch; ++b)
+                if (pl->segs[b].prestatus == CTCFA_ST_OK) Cbt = std::max(Cbt, (int)C[b]);
+            pl->lab_bytes = (Cbt * 4 + 15) / 16 * 16;
+            const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8;
+            pl->lds_bt = pl->rec_bytes + pl->lab_bytes + std::max(Tbt * 4, ring + 256);  // + 64 decision words, recompute wave -> walker
+        }
     }
     if (pl->lds_bt > eng->lds_limit) {
         delete pl;
@@ -605,7 +616,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
     if (pl->lds_bt > 48 * 1024)
-        PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ctcfa::backtrack_kernel),
+        PLAN_TRY(hipFuncSetAttribute(!pl->ckpt ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel<0>)
+                                     : pl->V <= 32 ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel<33>)
+                                                   : reinterpret_cast<const void*>(ctcfa::backtrack_kernel<65>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
     if (!pl->win_list.empty()) {
         PLAN_TRY(hipMalloc(&pl->d_win_list, sizeof(int32_t) * pl->win_list.size()));
@@ -722,12 +735,20 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.flags = pl->prm.flags;
     bp.L = pl->prm.score_min_mean_over_L;
     bp.rec_bytes = pl->rec_bytes;
+    bp.lab_bytes = pl->lab_bytes;
     bp.dur = pl->prm.index_duration;
     const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
                            pl->d_lastcol[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
                            want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
-    hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st, start,
-                          windowed ? nullptr : stop, 0, ba);
+    if (!pl->ckpt)
+        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<0>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
+                              start, windowed ? nullptr : stop, 0, ba);
+    else if (pl->V <= 32)
+        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<33>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
+                              start, windowed ? nullptr : stop, 0, ba);
+    else
+        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<65>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
+                              start, windowed ? nullptr : stop, 0, ba);
     HIP_TRY(pl->eng, hipGetLastError());
     if (windowed) {
         ctcfa::WinParams wp;

@@ -118,7 +118,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // order on gfx9, so one wave doing both pays an HBM write round trip in every load wait.)
 // dynamic LDS = (W+1) slots * kRows * (VP+1) * 8  +  boundary columns  +  small buffers.
 // ---------------------------------------------------------------------------------------
-template <int KH, int KL, int VP>
+template <int KH, int KL, int VP, bool CK = false>
 __global__ void __launch_bounds__((KH >= 10) ? 320 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
@@ -484,6 +484,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const int t = j * kRows + lane;
                     if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
                 }
+                if constexpr (CK) {  // the table row this block would have ended in
+                    uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) bp[k] = __float_as_uint(kProbMax);
+                }
                 lds_barrier();
                 continue;
             }
@@ -546,11 +551,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const float a = pl + em[k].x;
                     const float b = pk + em[k].y;
                     const float nw = max3f(a, b, kProbMax);
-                    const float rsw = em[k].x - (nw - pl);
-                    const float rst = em[k].y - (nw - pk);
-                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
-                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
-                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
+                    if constexpr (!CK) {
+                        const float rsw = em[k].x - (nw - pl);
+                        const float rst = em[k].y - (nw - pk);
+                        // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                        const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                        dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
+                    }
                     prev[k] = nw;
                 }
                 if ((i + 1) % 4 == 0) pub4.x = prev[K - 1];
@@ -564,12 +571,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 // consumed at the end of the block, and LLVM otherwise sinks the residual math of
                 // all 32 rows down to that store, keeping every operand alive (hundreds of spills).
 #pragma unroll
-                for (int k = 0; k < K; ++k) asm volatile("" : "+v"(dec[k]));
+                for (int k = 0; k < K; ++k) {
+                    if constexpr (CK) asm volatile("" : "+v"(prev[k]));  // (keeps the rows apart for the scheduler)
+                    else asm volatile("" : "+v"(dec[k]));
+                }
             }
             // decision words of this block (fire and forget: this wave never waits on vmcnt)
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
 #pragma unroll
-            for (int k = 0; k < K; ++k) bp[k] = dec[k];
+            for (int k = 0; k < K; ++k) bp[k] = CK ? __float_as_uint(prev[k]) : dec[k];
             if (w == wstar) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
                 const int t = j * kRows + lane;
                 if (lane < kRows && t >= 1 && t < T)
@@ -744,8 +754,28 @@ struct BtParams {
     uint32_t flags;
     int L;            // score_min_mean_over_L
     int rec_bytes;    // bytes reserved for rec[] (multiple of 16) in dynamic LDS
+    int lab_bytes;    // checkpoint mode: bytes reserved for the label copy that follows rec[] (multiple of 16), else 0
     double dur;       // index_duration
 };
+
+// Checkpoint mode (fill_kernel<.., CK = true>, V <= 64): the fill stores no decisions, only the
+// table row every 32-row block ends in.  The backtrack recomputes what it needs: the path drops at
+// most one column per row, so inside a block it stays within 32 columns of where it enters and
+// every cell it visits depends on 64 columns of the previous block's last row -- one wave, lane i
+// = column (pc - i), runs the fill's recurrence AND the residual comparison over those 32 rows
+// (same operations in the same order: bit-identical decisions), ~10 % of the cells the fill
+// touches.  Lanes whose left neighbours are outside the window go wrong one column per row; the
+// path is always ahead of that front (row r: garbage in lanes >= 63 - r, path in lanes <= 31 - r).
+// Waves 1-3 stage the emission rows of the coming blocks as (e, m) pairs in LDS meanwhile (row
+// pitch PB entries, the last one the start column's pseudo label, as in the fill).  One slot: wave
+// 0 takes a block's 32 pairs into registers at once, then the slot is free for the next block.
+// It shares its LDS with the char_probs copy of the later phases -- the kernel has to stay under
+// 15.8 KB of LDS to sit beside two fill workgroups on a CU.
+
+__device__ __forceinline__ float dpp_wave_shl1(float src) {
+    // lane i <- src[lane i+1]; lane 63 <- 0 (bound_ctrl: the DPP folds into the consuming VALU op)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x130, 0xf, 0xf, true));
+}
 
 __device__ __forceinline__ double np_pairwise_sum_le128(const float* a, int n) {
     // NumPy's pairwise summation for n <= 128 (fp64 accumulate of fp32-exact values), LDS input
@@ -856,7 +886,7 @@ struct BtArgs {
 // NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
 // `sync` separates the phases, `tick` is called between slices of work (the fused wave has to
 // take part in the fill workgroup's barriers while it lives).
-template <int NT, class Sync, class Tick>
+template <int NT, int PB, class Sync, class Tick>
 __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& sd, int tid, unsigned char* smem,
                                                float* red_v, int* red_t, int* sh_misc, Sync sync, Tick tick) {
     const BtParams& p = a.p;
@@ -874,8 +904,11 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     int32_t* __restrict__ t_end_out = a.t_end_out;
     int32_t* __restrict__ status_out = a.status_out;
     constexpr int kThreads = NT;
+    constexpr bool CK = PB > 0;
     int2* rec = reinterpret_cast<int2*>(smem);                   // per block: (entry column, switch mask)
-    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes);   // char_probs of this segment
+    int32_t* labs = reinterpret_cast<int32_t*>(smem + p.rec_bytes);             // checkpoint mode: label copy
+    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes + p.lab_bytes);    // char_probs of this segment
+    float2* ering = reinterpret_cast<float2*>(cps);              // checkpoint mode, phase A: [32][PB] (e, m)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = kThreads / 64;
@@ -941,8 +974,294 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     const int nblk = (T - 1 + kRows - 1) / kRows;
     for (int j = tid; j < nblk; j += kThreads) rec[j] = make_int2(-1, 0);
     for (int c = tid; c < C; c += kThreads) fol[c] = 0;
+    if constexpr (CK) {
+        for (int c = tid; c < C; c += kThreads) labs[c] = seg_lab[c];
+    }
     sync();
 
+    if constexpr (CK) {
+        // ---- phase A, checkpoint mode: all four waves --------------------------------------
+        // (per-block barriers order LDS only: the producers' loads and the checkpoint prefetches
+        // stay in flight across them)
+        float bv = red_v[0];
+        int bt = red_t[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) {
+            const float ov = red_v[q];
+            const int ot = red_t[q];
+            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
+                bv = ov;
+                bt = ot;
+            }
+        }
+        int t_end = __builtin_amdgcn_readfirstlane(bt);
+        if (p.flags & 4u) t_end = T - 1;
+        int pc = C - 1 + shift;
+        if (t_end >= 1) {
+            const int jstart = (t_end - 1) >> 5;
+            // Roles: wave 0 recomputes decision words, wave 1 walks them, waves 2-3 stage emissions.
+            // Step j (j = jstart .. 0): the walker walks block j while wave 0 recomputes block j - 1,
+            // which it has to start before the walk knows where the path leaves block j: its lane 0
+            // is the column where the path ENTERED block j (pcj), and the path then enters block
+            // j - 1 at lane x = columns dropped in block j.  Row r of a recomputed block is wrong in
+            // lanes >= 63 - r (their left neighbours lie outside the wave) and the path sits in lanes
+            // <= x + 31 - r: fine for x <= 31.  x == 32 (a SWITCH in every row of block j) raises
+            // sh_misc[3] and block j - 1 is recomputed from its exact entry column at the start of
+            // the next step (slow path, as for the first block).
+            // Two LDS-only barriers per step: A (emission slot filled, decision words of block j and
+            // its entry column published) and B (slot and word buffer read, both may be overwritten);
+            // a third one, F, in the steps that take the slow path.
+            uint32_t* wbuf = reinterpret_cast<uint32_t*>(ering + kRows * PB);  // 64 words right after the emission slot
+            if (wave >= 2) {
+                // ======== producers: wave 2 stages rows 0-15 of every block, wave 3 rows 16-31.  Block
+                // jb is read in step jb + 1; its loads are issued in step jb + 4 and written to the
+                // slot in step jb + 2 (two register sets, by block parity).  Lane v < V stages
+                // vocabulary entry v of its rows, lane V (if there is one) the start column's pseudo
+                // entry; everything under ONE lane mask per block: put + issue have to fit in a step.
+                __builtin_amdgcn_s_setprio(1);
+                constexpr int kHalf = kRows / 2;
+                const int r0 = (wave - 2) * kHalf;
+                float e0[kHalf], e1[kHalf];
+                const bool preamble = (p.flags & 2u) != 0;
+                const bool is_pseudo = lane == V;             // no such lane when V == 64
+                const int woff = is_pseudo ? PB - 1 : lane;
+                auto issue = [&](int jb, float (&e)[kHalf]) {
+                    if (jb >= 0 && lane < V) {
+#pragma unroll
+                        for (int r = 0; r < kHalf; ++r) {
+                            int t = jb * kRows + 1 + r0 + r;
+                            t = t < T ? t : T - 1;   // rows past the end: decisions nobody reads
+                            e[r] = seg_lpz[(int64_t)t * V + lane];
+                        }
+                    }
+                };
+                auto put = [&](int jb, const float (&e)[kHalf]) {
+                    if (jb < 0) return;
+                    float2* slot = ering + r0 * PB + woff;
+                    if (lane <= V) {
+#pragma unroll
+                        for (int r = 0; r < kHalf; ++r) {
+                            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
+                            const float m = max3f(lb, e[r], kProbMax);
+                            const float pm = preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax);  // start column's stay step
+                            slot[r * PB] = make_float2(is_pseudo ? -__builtin_inff() : e[r], is_pseudo ? pm : m);
+                        }
+                    }
+                    if (V == 64 && lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < kHalf; ++r) {
+                            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
+                            ering[(r0 + r) * PB + PB - 1] = make_float2(-__builtin_inff(),
+                                                                        preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                        }
+                    }
+                };
+                // V == 32 (the common case): a lane moves four consecutive entries of a row with one
+                // dwordx4, eight lanes share a row, eight rows per pass -- two passes per half block.
+                const int vq = lane & 7, vr = lane >> 3;
+                float4 q0[2], q1[2];
+                auto issue4 = [&](int jb, float4 (&e)[2]) {
+                    if (jb < 0) return;
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        int t = jb * kRows + 1 + r0 + ps * 8 + vr;
+                        t = t < T ? t : T - 1;
+                        e[ps] = *reinterpret_cast<const float4*>(seg_lpz + (int64_t)t * 32 + 4 * vq);
+                    }
+                };
+                auto put4 = [&](int jb, const float4 (&e)[2]) {
+                    if (jb < 0) return;
+                    const int bq = p.blank >> 2, bc = p.blank & 3;
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const float4 v = e[ps];
+                        const float own = bc == 0 ? v.x : bc == 1 ? v.y : bc == 2 ? v.z : v.w;
+                        const float lb = __shfl(own, (lane & ~7) | bq);     // the row's blank entry
+                        float2* row = ering + (r0 + ps * 8 + vr) * PB;
+                        row[4 * vq + 0] = make_float2(v.x, max3f(lb, v.x, kProbMax));
+                        row[4 * vq + 1] = make_float2(v.y, max3f(lb, v.y, kProbMax));
+                        row[4 * vq + 2] = make_float2(v.z, max3f(lb, v.z, kProbMax));
+                        row[4 * vq + 3] = make_float2(v.w, max3f(lb, v.w, kProbMax));
+                        if (vq == 0)  // start column: e = -inf, m = its stay step
+                            row[PB - 1] = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                    }
+                };
+                // set 0: blocks of jstart's parity, set 1: the others
+                auto run = [&](auto&& issue_f, auto&& put_f, auto& s0, auto& s1) {
+                    issue_f(jstart - 1, s1);
+                    put_f(jstart - 1, s1);
+                    issue_f(jstart - 3, s1);
+                    issue_f(jstart - 2, s0);
+                    auto step = [&](int j, auto& e) {
+                        lds_barrier();                              // A
+                        const int slow = sh_misc[3];
+                        lds_barrier();                              // B
+                        if (slow) lds_barrier();                    // F
+                        put_f(j - 2, e);
+                        issue_f(j - 4, e);
+                    };
+                    for (int j = jstart; j >= 0; j -= 2) {
+                        step(j, s0);
+                        if (j >= 1) step(j - 1, s1);
+                    }
+                };
+                if (PB == 33 && V == 32) run(issue4, put4, q0, q1);
+                else run(issue, put, e0, e1);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (wave == 1) {
+                // ======== walker: one v_readlane + four scalar operations per row ====================
+                __builtin_amdgcn_s_setprio(3);
+                int x = 0;
+                for (int j = jstart; j >= 0; --j) {
+                    lds_barrier();                              // A
+                    const int slow = sh_misc[3];
+                    if (slow) {
+                        lds_barrier();                          // F: block j recomputed from its exact entry column
+                        x = 0;
+                    }
+                    const uint32_t W = wbuf[lane];
+                    const int pcj = sh_misc[2];
+                    lds_barrier();                              // B (waits for the two reads above)
+                    uint32_t S = 0u;
+                    int pidx = 0;
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
+                        S |= w & (1u << i);
+                        pidx += (int)((w >> i) & 1u);
+                    }
+                    if (lane == 0) {
+                        rec[j] = make_int2(pcj, (int)S);
+                        sh_misc[2] = pcj - pidx;                    // entry column of block j - 1
+                        sh_misc[3] = (pidx >= kRows && j >= 1) ? 1 : 0;
+                    }
+                    x = pidx;
+                    pc = pcj - pidx;
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (lane == 0) {
+                    sh_misc[0] = t_end;
+                    sh_misc[1] = (pc - shift > 0);  // reached t == 0 in a label column: the package's IndexError
+                }
+            } else {
+                // ======== wave 0: recompute =========================================================
+                __builtin_amdgcn_s_setprio(3);
+                const uint32_t* seg_bits = bits + sd.bits_off;
+                const bool preamble = (p.flags & 2u) != 0;
+                auto cell = [&](float& prev, uint32_t& dec, float ee, float m) {
+                    const float pl = dpp_wave_shl1(prev);
+                    const float a = pl + ee;
+                    const float b = prev + m;
+                    const float nw = max3f(a, b, kProbMax);
+                    const float rsw = ee - (nw - pl);
+                    const float rst = m - (nw - prev);
+                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                    dec = __builtin_amdgcn_alignbit(dec, __float_as_uint(d), 31);
+                    prev = nw;
+                    asm volatile("" : "+v"(dec));  // pin the row (see the fill kernel): no sinking of 32 rows' residuals
+                };
+                // slow path: block jb with lane 0 = column `top`, operands straight from global memory
+                auto rows_slow = [&](int jb, int top) -> uint32_t {
+                    const int col = top - lane;
+                    const int c = col - shift;
+                    float prev;
+                    if (jb == 0) prev = c <= 0 ? 0.0f : kProbMax;                     // table row 0
+                    else prev = col >= 0 ? __uint_as_float(seg_bits[(int64_t)(jb - 1) * p.Cpad + col]) : 0.0f;
+                    const int lab = c <= 0 ? -1 : labs[c];
+                    float ee[kRows], lb[kRows];
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        int t = jb * kRows + 1 + i;
+                        t = t < T ? t : T - 1;
+                        lb[i] = seg_lpz[(int64_t)t * V + p.blank];
+                        ee[i] = seg_lpz[(int64_t)t * V + (lab < 0 ? 0 : lab)];
+                    }
+                    uint32_t dec = 0u;
+#pragma unroll
+                    for (int i = 0; i < kRows; ++i) {
+                        const float e1 = lab < 0 ? -__builtin_inff() : ee[i];
+                        const float m = lab < 0 ? (preamble ? 0.0f : __builtin_fmaxf(lb[i], kProbMax))
+                                                : max3f(lb[i], ee[i], kProbMax);
+                        cell(prev, dec, e1, m);
+                    }
+                    return c <= 0 ? 0u : dec;  // start column and left of it: STAY
+                };
+                {   // first block: exact entry column, rows after t_end are not part of the path
+                    const int b0 = 31 - ((t_end - 1) & 31);
+                    wbuf[lane] = rows_slow(jstart, pc) & ~((1u << b0) - 1u);
+                    if (lane == 0) {
+                        sh_misc[2] = pc;
+                        sh_misc[3] = 0;
+                    }
+                }
+                // Table row a block starts from = what the fill stored for the block before it,
+                // requested kDepth steps ahead for the 192 columns its lane 0 can still lie in and
+                // re-based on arrival.  (Branch-free and unconditional: a load under control flow
+                // makes the compiler wait for every outstanding load at the join; what must not be
+                // used is replaced on arrival.)
+#ifndef CTCFA_CK_DEPTH
+#define CTCFA_CK_DEPTH 2
+#endif
+                constexpr int kDepth = CTCFA_CK_DEPTH;
+                auto fetch = [&](int jb, int base, int part) -> uint32_t {  // start row of block jb
+                    const int col = base - 64 * part - lane;
+                    const uint32_t idx = (jb >= 1 && col >= 0) ? (uint32_t)((jb - 1) * p.Cpad + col) : 0u;  // < 2^31: one segment's words
+                    return seg_bits[idx];
+                };
+                uint32_t pf[kDepth][3];
+                int pbase[kDepth];
+                int j = jstart;
+#pragma unroll
+                for (int u = 0; u < kDepth; ++u) {
+                    pbase[u] = pc;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - u, pc, q);
+                }
+                while (j >= 0) {
+#pragma unroll
+                    for (int u = 0; u < kDepth; ++u) {
+                        if (j < 0) break;
+                        lds_barrier();                          // A
+                        if (sh_misc[3]) {                       // block j's words were computed for a window the path left
+                            wbuf[lane] = rows_slow(j, sh_misc[2]);
+                            lds_barrier();                      // F
+                        }
+                        const int pcj = sh_misc[2];             // entry column of block j = lane 0 of block j - 1
+                        const int src = (pbase[u] - pcj) + lane;  // 0 .. 191
+                        const uint32_t f0 = __shfl(pf[u][0], src & 63);
+                        const uint32_t f1 = __shfl(pf[u][1], src & 63);
+                        const uint32_t f2 = __shfl(pf[u][2], src & 63);
+                        float prev = __uint_as_float((src < 64) ? f0 : (src < 128) ? f1 : f2);
+                        const int col = pcj - lane;
+                        const int c = col - shift;                  // label column of this lane
+                        if (j == 1) prev = c <= 0 ? 0.0f : kProbMax;  // block 0 starts from table row 0
+                        if (col < 0) prev = 0.0f;                    // left of the padded table
+                        pbase[u] = pcj;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - kDepth, pcj, q);
+                        const int lab = c <= 0 ? PB - 1 : labs[c < C ? c : 0];  // c < C: the path never sits right of C-1
+                        const float2* erow = ering + lab;
+                        float2 emr[kRows];
+#pragma unroll
+                        for (int i = 0; i < kRows; ++i) emr[i] = erow[i * PB];
+                        lds_barrier();                          // B (waits for the reads above)
+                        if (j >= 1) {
+                            uint32_t dec = 0u;
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y);
+                            wbuf[lane] = c <= 0 ? 0u : dec;
+                        }
+                        --j;
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else if (wave == 1 && lane == 0) {
+            sh_misc[0] = t_end;
+            sh_misc[1] = (pc - shift > 0);
+        }
+    } else
     // ---- phase A (wave 0): the walk, one scalar step per run of STAYs ----------------------
     if (wave == 0) {
         float bv = red_v[0];
@@ -1116,14 +1435,15 @@ struct WaveSync {  // one wave: program order + completed memory operations is a
     }
 };
 
-__global__ void __launch_bounds__(kBtThreads)
+template <int PB>  // 0: decision words from the fill; 33 / 65: checkpoint mode, V <= 32 / V <= 64
+__global__ void __launch_bounds__(kBtThreads, 4)   // <= 128 VGPRs: two workgroups per CU beside the fill's
 backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_v[kBtThreads / 64];
     __shared__ int red_t[kBtThreads / 64];
-    __shared__ int sh_misc[2];  // [0] t_end, [1] bad
+    __shared__ int sh_misc[4];  // [0] t_end, [1] bad; checkpoint mode: [2] entry column of the block to walk, [3] slow-path flag
     const SegDesc sd = a.segs[blockIdx.x];
-    backtrack_body<kBtThreads>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
+    backtrack_body<kBtThreads, PB>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
 }
 
 

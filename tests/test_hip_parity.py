@@ -152,6 +152,56 @@ def test_one_hot_emissions_unique_path(pkg, oracle):
     _check(pkg, oracle, [(lpz, gt, ub)], res)
 
 
+@pytest.mark.parametrize("V", [20, 32, 38, 64])
+def test_bursts_of_switches_across_block_boundaries(pkg, oracle, V):
+    """Planted paths that switch in every frame for 28..40 frames in a row, at all phases relative to
+    the 32-row blocks: in checkpoint mode (V <= 64) the backtrack recomputes a block's decisions in a
+    64-column window that starts where the path entered the block BEFORE; 32 switches in one block
+    push the path out of that window and the block is recomputed from its exact entry column."""
+    rng = np.random.default_rng(77 + V + FUZZ_SALT)
+    segs = []
+    for s in range(6):
+        gt, ub = pkg.synthetic.make_labels(rng, 10, 30, V)
+        C = len(gt)
+        T = 3 * C + int(rng.integers(0, 40))
+        firsts, t = [], 1 + int(rng.integers(0, 32))
+        while len(firsts) < C - 1:
+            run = min(int(rng.integers(28, 41)), C - 1 - len(firsts))
+            firsts.extend(range(t, t + run))
+            t += run + int(rng.integers(1, 70))
+        firsts = np.asarray(firsts)
+        assert firsts[-1] < T
+        logits = np.full((T, V), -30.0, np.float32) + rng.normal(0, 0.5, (T, V)).astype(np.float32)
+        logits[:, 0] += 30.0                     # blank everywhere ...
+        logits[firsts, 0] -= 30.0
+        logits[firsts, gt[1:]] += 30.0           # ... except the first frame of each label
+        lpz = (logits - np.log(np.exp(logits.astype(np.float64)).sum(1, keepdims=True))).astype(np.float32)
+        segs.append((lpz, gt, ub))
+    for kw in (dict(), dict(backtrack_from_max_t=True), dict(preamble_transition_cost_zero=False)):
+        res = _run(pkg, segs, **kw)
+        _check(pkg, oracle, segs, res, cfg_kw={k: int(v) for k, v in kw.items()})
+        assert all(r["status"] == 0 for r in res)
+
+
+def test_checkpoint_mode_and_decision_word_mode_agree(pkg, oracle, monkeypatch):
+    """V <= 64 runs in checkpoint mode (the fill stores table rows, the backtrack recomputes its
+    decisions); CTCFA_DECISION_BITS=1 forces the decision-word mode that wider vocabularies use."""
+    syn = pkg.synthetic
+    rng = np.random.default_rng(9 + FUZZ_SALT)
+    segs = [syn.make_segment(900 + s, int(rng.integers(40, 1500)), 32, int(rng.integers(1, 9)), int(rng.integers(3, 40)))
+            for s in range(24)]
+    segs = [s for s in segs if len(s[1]) <= s[0].shape[0]]
+    a = _run(pkg, segs)
+    monkeypatch.setenv("CTCFA_DECISION_BITS", "1")
+    b = _run(pkg, segs)
+    monkeypatch.delenv("CTCFA_DECISION_BITS")
+    _check(pkg, oracle, segs, a)
+    for x, y in zip(a, b):
+        assert x["status"] == y["status"] and x["t_end"] == y["t_end"]
+        for k in ("frame_of_label", "char_prob", "state", "seg_start", "seg_end", "seg_score"):
+            assert np.array_equal(x[k], y[k]), k
+
+
 def test_backtrack_from_max_t(pkg, oracle):
     syn = pkg.synthetic
     segs = [syn.make_segment(400 + s, 350, 32, 3, 22) for s in range(3)]

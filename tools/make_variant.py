@@ -45,12 +45,15 @@ def patch_C(k, h):
 
 
 def patch_D(k, h):
-    k = sub(k, """                    const float rsw = em[k].x - (nw - pl);
-                    const float rst = em[k].y - (nw - pk);
-                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
-                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
-                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);""",
-            "                    dec[k] ^= __float_as_uint(nw);")
+    """decision-word mode only (run with CTCFA_DECISION_BITS=1)"""
+    k = sub(k, """                    if constexpr (!CK) {
+                        const float rsw = em[k].x - (nw - pl);
+                        const float rst = em[k].y - (nw - pk);
+                        // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                        const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                        dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
+                    }""",
+            "                    if constexpr (!CK) dec[k] ^= __float_as_uint(nw);")
     return k, h
 
 
@@ -130,9 +133,10 @@ def patch_stamp(k, h):
     k = sub(k, "                if (w == wstar) {\n                    const int t = j * kRows + lane;\n                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;\n                }", "")
     k = sub(k, "    if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;", "")
     # stamps land in the caller's char_prob buffer; the backtrack kernel is not launched
-    h = sub(h, "a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,\n                       (pl->prm.flags",
-            "a.d_labels, pl->d_bits[ws], a.d_char_prob, pl->V, pl->prm.blank,\n                       (pl->prm.flags")
-    h = sub(h, "    if ((rc = launch_backtrack(pl, a, want_seg, 0, st)) != CTCFA_OK) return rc;", "    (void)want_seg;")
+    h = sub(h, "pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,",
+            "pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], a.d_char_prob, pl->V, pl->prm.blank,")
+    h = sub(h, "    if ((rc = launch_backtrack(pl, a, want_seg, 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr)) != CTCFA_OK) return rc;",
+            "    (void)want_seg;")
     return k, h
 
 

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 eng = pkg._native.Engine(0)
 
 
-def run(segs, K, steps=6):
+def run(segs, K, steps=30):
     T = [s[0].shape[0] for s in segs]
     C = [len(s[1]) for s in segs]
     U = [len(s[2]) - 1 for s in segs]
