@@ -441,10 +441,6 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
            : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
     pl->have_utt = (U != nullptr);
-    // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
-    // of decision words and the backtrack recomputes the decisions along the path.
-    // CTCFA_DECISION_BITS=1 forces the decision-word mode the wider vocabularies use (tests).
-    pl->ckpt = !gather && pl->VP <= 64 && !std::getenv("CTCFA_DECISION_BITS");
 
     int Cmax = 2, Tmax = 1;
     for (int b = 0; b < batch; ++b) {
@@ -456,6 +452,19 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         Tmax = std::max(Tmax, (int)T[b]);
     }
     pl->gather = gather;
+    // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
+    // of decision words (3.5 instead of 9.5 VALU per cell) and the backtrack recomputes the decisions
+    // along the path -- a longer, serial backtrack.  It pays where the fill is what a batch waits
+    // for: many label columns per segment, or enough segments per CU (measured, pipelined schedule,
+    // segments x columns: +11 % at 512 x 640, +35 % at 512 x 1242, +51 % at 4096 x 640, +12..38 % at
+    // 1024..2048 x 254; 0 at 512 x 512, -3..-5 % at 512 x 128..380, -27 % for 4096 word-level rows of
+    // ~425 frames x 54 columns, where the backtracks are the longer kernel in either mode).
+    // CTCFA_CHECKPOINT=1 / CTCFA_DECISION_BITS=1 force one mode (tests, tuning).
+    {
+        const bool can = !gather && pl->VP <= 64;
+        const bool pays = Cmax >= 544 || (int64_t)batch * Cmax >= 256 * 1024;
+        pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
+    }
     ShapeChoice shape{0, 0, false};
     if (gather) {
         const int W = std::max(1, (Cmax - 1 + 63) / 64);  // label columns 1 .. C-1, one per lane
@@ -574,7 +583,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             int Cbt = 1;
             for (int b = 0; b < batch; ++b)
                 if (pl->segs[b].prestatus == CTCFA_ST_OK) Cbt = std::max(Cbt, (int)C[b]);
-            pl->lab_bytes = (Cbt * 4 + 15) / 16 * 16;
+            pl->lab_bytes = (Cbt + 15) / 16 * 16;   // one byte per label
             const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8;
             pl->lds_bt = pl->rec_bytes + pl->lab_bytes + std::max(Tbt * 4, ring + 256);  // + 64 decision words, recompute wave -> walker
         }

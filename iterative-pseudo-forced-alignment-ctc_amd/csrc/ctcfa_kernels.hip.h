@@ -906,7 +906,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     constexpr int kThreads = NT;
     constexpr bool CK = PB > 0;
     int2* rec = reinterpret_cast<int2*>(smem);                   // per block: (entry column, switch mask)
-    int32_t* labs = reinterpret_cast<int32_t*>(smem + p.rec_bytes);             // checkpoint mode: label copy
+    uint8_t* labs = smem + p.rec_bytes;                                         // checkpoint mode: label copy (V <= 64: one byte each)
     float* cps = reinterpret_cast<float*>(smem + p.rec_bytes + p.lab_bytes);    // char_probs of this segment
     float2* ering = reinterpret_cast<float2*>(cps);              // checkpoint mode, phase A: [32][PB] (e, m)
     const int lane = tid & 63;
@@ -975,7 +975,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     for (int j = tid; j < nblk; j += kThreads) rec[j] = make_int2(-1, 0);
     for (int c = tid; c < C; c += kThreads) fol[c] = 0;
     if constexpr (CK) {
-        for (int c = tid; c < C; c += kThreads) labs[c] = seg_lab[c];
+        for (int c = tid; c < C; c += kThreads) labs[c] = (uint8_t)seg_lab[c];  // [0] = -1 is never looked up
     }
     sync();
 
@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                     float prev;
                     if (jb == 0) prev = c <= 0 ? 0.0f : kProbMax;                     // table row 0
                     else prev = col >= 0 ? __uint_as_float(seg_bits[(int64_t)(jb - 1) * p.Cpad + col]) : 0.0f;
-                    const int lab = c <= 0 ? -1 : labs[c];
+                    const int lab = c <= 0 ? -1 : (int)labs[c];
                     float ee[kRows], lb[kRows];
 #pragma unroll
                     for (int i = 0; i < kRows; ++i) {
@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         pbase[u] = pcj;
 #pragma unroll
                         for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - kDepth, pcj, q);
-                        const int lab = c <= 0 ? PB - 1 : labs[c < C ? c : 0];  // c < C: the path never sits right of C-1
+                        const int lab = c <= 0 ? PB - 1 : (int)labs[c < C ? c : 0];  // c < C: the path never sits right of C-1
                         const float2* erow = ering + lab;
                         float2 emr[kRows];
 #pragma unroll

@@ -13,6 +13,16 @@ FUZZ_SALT = int(__import__("os").environ.get("CTCFA_FUZZ_SALT", "0"))  # soak ru
 DUR = 320.4769 / 16000
 
 
+@pytest.fixture(autouse=True, params=["auto", "checkpoint"])
+def dp_mode(request, monkeypatch):
+    """Every test of this file runs twice: with the plan's own choice between decision-word mode
+    and checkpoint mode (small test batches mostly get decision words), and with checkpoint mode
+    forced wherever it exists (vocabularies up to 64 entries)."""
+    if request.param == "checkpoint":
+        monkeypatch.setenv("CTCFA_CHECKPOINT", "1")
+    return request.param
+
+
 def _check(pkg, oracle, segs, res, cfg_kw=None):
     ocfg = oracle.make_config(index_duration=DUR, **(cfg_kw or {}))
     for i, ((lpz, gt, ub), r) in enumerate(zip(segs, res)):
@@ -191,6 +201,7 @@ def test_checkpoint_mode_and_decision_word_mode_agree(pkg, oracle, monkeypatch):
     segs = [syn.make_segment(900 + s, int(rng.integers(40, 1500)), 32, int(rng.integers(1, 9)), int(rng.integers(3, 40)))
             for s in range(24)]
     segs = [s for s in segs if len(s[1]) <= s[0].shape[0]]
+    monkeypatch.setenv("CTCFA_CHECKPOINT", "1")
     a = _run(pkg, segs)
     monkeypatch.setenv("CTCFA_DECISION_BITS", "1")
     b = _run(pkg, segs)
