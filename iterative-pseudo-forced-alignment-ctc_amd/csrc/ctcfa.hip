@@ -236,8 +236,8 @@ int vgprs_of(int K) {  // compiled register counts, rounded up (allocation granu
     }
 }
 
-bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k, bool allow_mixed, bool ckpt,
-                ShapeChoice* out) {
+bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_cu, int force_k, bool allow_mixed,
+                bool ckpt, ShapeChoice* out) {
     double best_cost = -1.0;
     ShapeChoice best{0, 0, false};
     const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
@@ -251,7 +251,12 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int num_cu, int force_k,
     auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
         const int lds = lds_bytes_fill(stages, VP);
         if (lds > lds_limit) return;
-        const int g_lds = lds_limit / lds;
+        // In the pipelined schedule a CU hosts, beside G fill workgroups, G backtrack workgroups of
+        // the previous batch (lds_beside bytes each; LDS is handed out in 512-byte units).  A shape
+        // whose LDS leaves no room for them serialises the two kernels (V = 38, seven ring slots:
+        // 0.38 ms per step instead of the 0.32 ms of fill + backtrack one after the other).
+        auto r512 = [](int x) { return (x + 511) / 512 * 512; };
+        const int g_lds = std::max(lds_limit / (r512(lds) + r512(lds_beside)), 1);
         const int g_wave = 32 / waves_per_wg;
         const int g_vgpr = 4 * (512 / vgprs_of(K)) / waves_per_wg;
         const int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
@@ -462,8 +467,19 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // CTCFA_CHECKPOINT=1 / CTCFA_DECISION_BITS=1 force one mode (tests, tuning).
     {
         const bool can = !gather && pl->VP <= 64;
-        const bool pays = Cmax >= 544 || (int64_t)batch * Cmax >= 256 * 1024;
+        // (the host-buffer entry runs fill and backtrack one after the other: there the longer
+        // backtrack only pays once the fill is several times its length)
+        const bool pays = use_scratch ? (int64_t)batch * Cmax >= 1024 * 1024
+                                      : Cmax >= 544 || ((int64_t)batch * Cmax >= 256 * 1024 && Tmax >= 1000);
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
+    }
+    // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
+    int bt_lds_estimate;
+    {
+        const int Tb = std::min(Tmax, std::max(1, (int)params->min_window_size));  // longer segments: windowed kernel
+        const int rec = ((Tb + ctcfa::kRows - 1) / ctcfa::kRows * 8 + 15) / 16 * 16;
+        const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8 + 256;
+        bt_lds_estimate = pl->ckpt ? rec + (Cmax + 15) / 16 * 16 + std::max(Tb * 4, ring) : rec + Tb * 4;
     }
     ShapeChoice shape{0, 0, false};
     if (gather) {
@@ -473,8 +489,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128: at most 961 label columns per segment");
         }
         shape = {1, W, false};
-    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, eng->num_cu, force_k, !std::getenv("CTCFA_NO_MIXED"),
-                           pl->ckpt, &shape)) {
+    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, bt_lds_estimate, eng->num_cu, force_k,
+                           !std::getenv("CTCFA_NO_MIXED"), pl->ckpt, &shape)) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
     }

@@ -6,14 +6,18 @@
 // (requirements.txt:13; reached from src/iterative_utterance_alignment.py:216), plus the
 // transition the package's backtrack would infer at (t,c) from fp32 residuals:
 //   SWITCH  iff  | max(lb,e) - (table[t,c]-table[t-1,c]) |  >  | e - (table[t,c]-table[t-1,c-1]) |
-// That predicate is evaluated at fill time, while all four operands are in registers,
-// and kept as ONE BIT per cell; the fp32 trellis itself never leaves the chip.
+// Decision-word mode: that predicate is evaluated at fill time, while all four operands are in
+// registers, and kept as ONE BIT per cell.  Checkpoint mode (vocabulary <= 64, chosen per plan):
+// the fill keeps only the table row every 32-row block ends in (the same 32 bits per block and
+// column) and the backtrack re-runs recurrence + predicate over the 64 columns x 32 rows around
+// the path.  Either way the fp32 trellis itself never leaves the chip.
 //
 // Kernels:
-//   fill_kernel<KH,KL,VP>   T <= min_window_size, vocabulary <= 128: the hot one
-//   fill_gather_kernel      same, vocabulary > 128 (no LDS staging of vocabulary rows)
-//   backtrack_kernel        end cell, walk over the decision bits, per-frame outputs, scores
-//   windowed_kernel         T > min_window_size: the package's windowed regime, literally
+//   fill_kernel<KH,KL,VP,CK>  T <= min_window_size, vocabulary <= 128: the hot one
+//   fill_gather_kernel        same, vocabulary > 128 (no LDS staging of vocabulary rows)
+//   backtrack_kernel<PB>      end cell, walk (over decision words, or recomputing them from the
+//                             checkpoint rows), per-frame outputs, scores
+//   windowed_kernel           T > min_window_size: the package's windowed regime, literally
 //
 // Mapping of fill_kernel (CDNA4, 64-wide waves, no MFMA: a max-plus scan is not a contraction):
 //   * one workgroup per segment; its padded columns are cut into tiles, a compute wave owns
@@ -28,7 +32,8 @@
 //     the "start column" pseudo-label (e = -inf, m = 0) that makes column 0
 //     (ground_truth == -1) and the left padding reproduce table[t,0];
 //   * decisions are shifted into a per-(lane,k) register (v_alignbit) and stored every
-//     32 rows as words bits[block][column]; HBM traffic per segment is
+//     32 rows as words bits[block][column] (checkpoint mode: the table value of the block's last
+//     row goes there instead); HBM traffic per segment is
 //     4*T*V (emissions, once) + T*Cpad/8 (bits) + 4*T (last-column scores);
 //   * blocks that cannot matter are skipped exactly (dead zone behind the end cell's cone;
 //     the -1e9 zone above the diagonal while every emission so far is <= 0).
