@@ -251,15 +251,19 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
     auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
         const int lds = lds_bytes_fill(stages, VP);
         if (lds > lds_limit) return;
-        // In the pipelined schedule a CU hosts, beside G fill workgroups, G backtrack workgroups of
-        // the previous batch (lds_beside bytes each; LDS is handed out in 512-byte units).  A shape
-        // whose LDS leaves no room for them serialises the two kernels (V = 38, seven ring slots:
-        // 0.38 ms per step instead of the 0.32 ms of fill + backtrack one after the other).
-        auto r512 = [](int x) { return (x + 511) / 512 * 512; };
-        const int g_lds = std::max(lds_limit / (r512(lds) + r512(lds_beside)), 1);
+        auto r512 = [](int x) { return (x + 511) / 512 * 512; };  // LDS is handed out in 512-byte units
+        const int g_lds = std::max(lds_limit / r512(lds), 1);
         const int g_wave = 32 / waves_per_wg;
         const int g_vgpr = 4 * (512 / vgprs_of(K)) / waves_per_wg;
-        const int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
+        int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
+        // Pipelined schedule: the backtrack workgroups of the previous batch (lds_beside bytes each)
+        // run beside this fill.  When the whole batch is resident at once they only get in if the
+        // fill workgroups leave them room; if not, the two kernels take turns (V = 38 with seven ring
+        // slots: 0.38 ms per step instead of 0.28).  With several rounds of fill workgroups they slip
+        // in as those retire (B = 4096: K = 4, W = 3 at four per CU stays the best shape).
+        if (G >= wg_per_cu_needed && wg_per_cu_needed > 1 &&
+            wg_per_cu_needed * r512(lds) + std::min(wg_per_cu_needed, 2) * r512(lds_beside) > lds_limit)
+            G = wg_per_cu_needed - 1;
         const int g_eff = std::min(G, wg_per_cu_needed);
         const int rounds = (wg_per_cu_needed + G - 1) / G;
         if (single_round_only && rounds > 1) return;
