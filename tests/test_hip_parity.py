@@ -213,6 +213,18 @@ def test_checkpoint_mode_and_decision_word_mode_agree(pkg, oracle, monkeypatch):
             assert np.array_equal(x[k], y[k]), k
 
 
+def test_benchmark_shaped_segments_match_oracle(pkg, oracle):
+    """BASELINE.json configs[2] geometry (3000 frames x 640 label columns), every segment checked
+    against the oracle -- in decision-word mode (what the host-buffer entry picks for 8 segments) and,
+    through the dp_mode fixture, in checkpoint mode (what the benchmark's 512-segment plan runs in)."""
+    syn = pkg.synthetic
+    segs = [syn.make_segment(7000 + FUZZ_SALT * 100 + s, 3000, 32, 22, 28) for s in range(8)]
+    for kw in (dict(), dict(backtrack_from_max_t=True), dict(preamble_transition_cost_zero=False)):
+        res = _run(pkg, segs, **kw)
+        _check(pkg, oracle, segs, res, cfg_kw={k: int(v) for k, v in kw.items()})
+        assert all(r["status"] == 0 for r in res)
+
+
 def test_backtrack_from_max_t(pkg, oracle):
     syn = pkg.synthetic
     segs = [syn.make_segment(400 + s, 350, 32, 3, 22) for s in range(3)]
