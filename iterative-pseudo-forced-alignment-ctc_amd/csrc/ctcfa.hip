@@ -464,17 +464,18 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
     // of decision words (3.5 instead of 9.5 VALU per cell) and the backtrack recomputes the decisions
     // along the path -- a longer, serial backtrack.  It pays where the fill is what a batch waits
-    // for: many label columns per segment, or enough segments per CU (measured, pipelined schedule,
-    // segments x columns: +11 % at 512 x 640, +35 % at 512 x 1242, +51 % at 4096 x 640, +12..38 % at
-    // 1024..2048 x 254; 0 at 512 x 512, -3..-5 % at 512 x 128..380, -27 % for 4096 word-level rows of
-    // ~425 frames x 54 columns, where the backtracks are the longer kernel in either mode).
+    // for: many label columns per segment, or enough segments per CU (profiles/r01_modes.txt, pipelined
+    // schedule, segments x columns: +11 % at 512 x 640, +35 % at 512 x 1242, +50 % at 4096 x 640,
+    // +11..31 % at 1024..1536 x 254; 0 at 512 x 512, -1..-5 % at 512 x 128..380, -12 % at 2048 x 128,
+    // -39 % for 4096 word-level rows of ~425 frames x 54 columns, where the backtracks are the longer
+    // kernel in either mode).
     // CTCFA_CHECKPOINT=1 / CTCFA_DECISION_BITS=1 force one mode (tests, tuning).
     {
         const bool can = !gather && pl->VP <= 64;
         // (the host-buffer entry runs fill and backtrack one after the other: there the longer
         // backtrack only pays once the fill is several times its length)
         const bool pays = use_scratch ? (int64_t)batch * Cmax >= 1024 * 1024
-                                      : Cmax >= 544 || ((int64_t)batch * Cmax >= 256 * 1024 && Tmax >= 1000);
+                                      : Cmax >= 544 || ((int64_t)batch * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
     }
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
