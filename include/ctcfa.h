@@ -79,7 +79,7 @@ typedef struct ctcfa_plan_info {
     int32_t vocab_pitch;     /* LDS row pitch in entries            */
     int32_t lds_bytes;       /* dynamic LDS of the fill kernel      */
     int32_t n_blocks_max;    /* 32-row blocks of the longest segment */
-    int64_t workspace_bytes; /* decision bits + last-column scores  */
+    int64_t workspace_bytes; /* trellis trace words (decision bits / checkpoint rows) + last-column scores */
     int64_t algorithmic_bytes; /* sum_b 4TV + TC/8 + 4T + 8C + 4T */
     int64_t total_frames;
 } ctcfa_plan_info;
