@@ -9,6 +9,7 @@ bench.py --no-check or tools/stamps.py):
     A      no cross-wave boundary LDS traffic in the row loop (no bnd read, no publish)
     C      no emission gathers (operands derived from registers)
     D      recurrence only: drop the residual/decision math (4 VALU per cell)
+    nowait the pipelined entry's fill does not wait for the workspace hand-over (timing only)
     stamp  s_memtime stamps around compute / barrier of every step (see tools/stamps.py);
            host passes char_prob as the stamp buffer and skips the backtrack kernel
 """
@@ -54,6 +55,13 @@ def patch_D(k, h):
                         dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
                     }""",
             "                    if constexpr (!CK) dec[k] ^= __float_as_uint(nw);")
+    return k, h
+
+
+def patch_nowait(k, h):
+    """timing only (results race): the fill of run k does not wait for the backtrack of run k-2 to
+    release its workspace -- shows how much of a pipelined step is that hand-over"""
+    h = sub(h, "    if (pl->bt_pending[q] && hipEventQuery(pl->bt_done_ev[q]) != hipSuccess)\n        HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));", "")
     return k, h
 
 
@@ -152,7 +160,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"nowait": patch_nowait, "btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():
