@@ -51,6 +51,11 @@ extern "C" {
                                               caught at iterative_utterance_alignment.py:390 */
 #define CTCFA_ST_BACKTRACK_FAILED 2        /* IndexError re-raised by ctc_segmentation()      */
 #define CTCFA_ST_WINDOWED_UNSUPPORTED 3    /* windowed regime with T*4 bytes > LDS (T > ~40 000 frames) */
+#define CTCFA_ST_TEXT_TOO_LONG 4           /* more label columns than one fill workgroup covers (> ~7 400
+                                              with T <= min_window_size); the other segments of the batch
+                                              are aligned */
+#define CTCFA_ST_INTERNAL 5                /* a wave of the fill kernel gave up waiting for a progress
+                                              counter (bounded spins: a bug must not hang the GPU) */
 
 /* flags (CtcSegmentationParameters.flags + the backtrack switch) */
 #define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; not yet supported */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTCFA_LIB") or os.path.join(_HERE, "csrc", "libctcfa_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, 1, 2, 3, 4
-ST_OK, ST_AUDIO_SHORTER_THAN_TEXT, ST_BACKTRACK_FAILED, ST_WINDOWED_UNSUPPORTED = 0, 1, 2, 3
+ST_OK, ST_AUDIO_SHORTER_THAN_TEXT, ST_BACKTRACK_FAILED, ST_WINDOWED_UNSUPPORTED, ST_TEXT_TOO_LONG, ST_INTERNAL = 0, 1, 2, 3, 4, 5
 FLAG_BLANK_TRANSITION_COST_ZERO, FLAG_PREAMBLE_TRANSITION_COST_ZERO, FLAG_BACKTRACK_FROM_MAX_T = 1, 2, 4
 
 # every symbol include/ctcfa.h declares

@@ -76,7 +76,6 @@ struct ctcfa_plan {
     int64_t win_table_floats = 0, win_cols = 0;
     int lds_win = 0;
     bool gather = false;              // wide vocabulary: fill_gather_kernel
-    int KL = 0;                       // columns per lane of the light tiles (== K for uniform shapes)
     ctcfa::FillRoles roles{};         // what each wave of a fill workgroup does
     ctcfa::FillRoles* d_roles = nullptr;
 };
@@ -104,205 +103,161 @@ using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*,
 template <int VP, bool CK>
 FillFn fill_for_k(int K) {
     switch (K) {
-        case 1: return ctcfa::fill_kernel<1, 1, VP, CK>;
-        case 2: return ctcfa::fill_kernel<2, 2, VP, CK>;
-        case 3: return ctcfa::fill_kernel<3, 3, VP, CK>;
-        case 4: return ctcfa::fill_kernel<4, 4, VP, CK>;
-        case 5: return ctcfa::fill_kernel<5, 5, VP, CK>;
-        case 6: return ctcfa::fill_kernel<6, 6, VP, CK>;
-        case 8: return ctcfa::fill_kernel<8, 8, VP, CK>;
-        case 10: return ctcfa::fill_kernel<10, 10, VP, CK>;
-        case 12: return ctcfa::fill_kernel<12, 12, VP, CK>;
-        case 16: return ctcfa::fill_kernel<16, 16, VP, CK>;
-        default: return nullptr;
-    }
-}
-
-template <int VP, bool CK>
-FillFn fill_mixed(int KH) {
-    switch (KH) {
-        case 2: return ctcfa::fill_kernel<2, 1, VP, CK>;
-        case 4: return ctcfa::fill_kernel<4, 2, VP, CK>;
+        case 1: return ctcfa::fill_kernel<1, VP, CK>;
+        case 2: return ctcfa::fill_kernel<2, VP, CK>;
+        case 3: return ctcfa::fill_kernel<3, VP, CK>;
+        case 4: return ctcfa::fill_kernel<4, VP, CK>;
+        case 5: return ctcfa::fill_kernel<5, VP, CK>;
+        case 6: return ctcfa::fill_kernel<6, VP, CK>;
+        case 8: return ctcfa::fill_kernel<8, VP, CK>;
+        case 10: return ctcfa::fill_kernel<10, VP, CK>;
+        case 12: return ctcfa::fill_kernel<12, VP, CK>;
+        case 16: return ctcfa::fill_kernel<16, VP, CK>;
         default: return nullptr;
     }
 }
 
 template <int VP>
-FillFn fill_any(int KH, int KL, bool ck) {
+FillFn fill_any(int K, bool ck) {
     if constexpr (VP <= 64) {
-        if (ck) return KL == KH ? fill_for_k<VP, true>(KH) : fill_mixed<VP, true>(KH);
+        if (ck) return fill_for_k<VP, true>(K);
     }
-    return KL == KH ? fill_for_k<VP, false>(KH) : fill_mixed<VP, false>(KH);
+    return fill_for_k<VP, false>(K);
 }
 
-// KL == KH: uniform tiles; KL == KH / 2: the mixed 8-wave shape
-FillFn select_fill(int KH, int KL, int VP, bool ck) {
+FillFn select_fill(int K, int VP, bool ck) {
     switch (VP) {
-        case 32: return fill_any<32>(KH, KL, ck);
+        case 32: return fill_any<32>(K, ck);
 #ifndef CTCFA_DEV_VP32_ONLY  // tuning builds (tools/make_variant.py): one pitch compiles in a fifth of the time
-        case 40: return fill_any<40>(KH, KL, ck);
-        case 48: return fill_any<48>(KH, KL, ck);
-        case 56: return fill_any<56>(KH, KL, ck);
-        case 64: return fill_any<64>(KH, KL, ck);
-        case 80: return fill_any<80>(KH, KL, ck);
-        case 96: return fill_any<96>(KH, KL, ck);
-        case 112: return fill_any<112>(KH, KL, ck);
-        case 128: return fill_any<128>(KH, KL, ck);
+        case 40: return fill_any<40>(K, ck);
+        case 48: return fill_any<48>(K, ck);
+        case 56: return fill_any<56>(K, ck);
+        case 64: return fill_any<64>(K, ck);
+        case 80: return fill_any<80>(K, ck);
+        case 96: return fill_any<96>(K, ck);
+        case 112: return fill_any<112>(K, ck);
+        case 128: return fill_any<128>(K, ck);
 #endif
         default: return nullptr;
     }
 }
 
-// Role tables.  Uniform: waves 0..W-1 = stages 0..W-1, wave W = producer.
-ctcfa::FillRoles uniform_roles(int K, int W) {
+// columns a tile of K columns per lane adds to the trellis (its halo lanes are copies)
+int tile_useful_cols(int K) { return (64 - ctcfa::halo_lanes(K)) * K; }
+
+// Role table.  Workgroups of 4 or 8 waves land evenly on the four SIMDs of a CU ({w, w+4} share
+// one, and the neighbour workgroup on the same CU is rotated by one SIMD: tools/hwid_probe.hip), so
+// small tile counts are padded with waves that leave at once: tiles first one per SIMD (waves
+// 0..3), then the second wave of SIMD pairs 0 and 1 (waves 4, 6); the producer(s) take the second
+// wave of the other pairs (waves 5, 7) -- with the rotation every SIMD of the CU ends up with the
+// same number of tiles for W = 4 and W = 6.
+ctcfa::FillRoles tile_roles(int K, int W, int NS, int nprod) {
     ctcfa::FillRoles r{};
-    r.nwaves = W + 1;
+    const int U = tile_useful_cols(K);
+    const int XW = ctcfa::halo_lanes(K) * K;
     r.nstages = W;
-    r.cpad = 64 * K * W;
-    for (int w = 0; w < W; ++w) r.wave[w] = {ctcfa::kRoleHeavy, (int8_t)w, (int16_t)(w * 64 * K)};
-    r.wave[W] = {ctcfa::kRoleProducer, 0, 0};
+    r.cpad = W * U;
+    r.nslots = NS;
+    r.nprod = nprod;
+    int order[16];
+    bool padded8 = false;
+    if (W + nprod <= 4) {
+        r.nwaves = 4;
+        for (int i = 0; i < 4; ++i) order[i] = i;
+    } else if (W + nprod <= 8 && W <= 6) {
+        r.nwaves = 8;
+        padded8 = true;
+        const int o[8] = {0, 1, 2, 3, 4, 6, 5, 7};
+        for (int i = 0; i < 8; ++i) order[i] = o[i];
+    } else {
+        r.nwaves = W + nprod;
+        for (int i = 0; i < r.nwaves; ++i) order[i] = i;
+    }
+    for (int i = 0; i < r.nwaves; ++i) r.wave[i] = {ctcfa::kRoleIdle, 0, 0};
+    for (int w = 0; w < W; ++w) r.wave[order[w]] = {ctcfa::kRoleTile, (int8_t)w, (int16_t)(w * U - XW)};
+    if (padded8) {   // producers: second wave of SIMD pairs 2 and 3
+        r.wave[5] = {ctcfa::kRoleProducer, 0, 0};
+        if (nprod == 2) r.wave[7] = {ctcfa::kRoleProducer, 1, 0};
+    } else {
+        for (int p = 0; p < nprod; ++p) r.wave[order[W + p]] = {ctcfa::kRoleProducer, (int8_t)p, 0};
+    }
     return r;
-}
-
-// Mixed, 8 waves: 4 heavy tiles (KH) then 2 light ones (KL), same 320*KH columns as five
-// uniform tiles.  Waves {w, w+4} share a SIMD; the pairs are (H,H), (L,producer), (H,H), (L,idle).
-ctcfa::FillRoles mixed8_roles(int KH, int KL) {
-    ctcfa::FillRoles r{};
-    r.nwaves = 8;
-    r.nstages = 6;
-    r.cpad = 64 * (4 * KH + 2 * KL);
-    const int heavy_wave[4] = {0, 2, 4, 6};  // stage 0 with stage 2 on one SIMD, 1 with 3 on another
-    for (int i = 0; i < 4; ++i) r.wave[heavy_wave[i]] = {ctcfa::kRoleHeavy, (int8_t)i, (int16_t)(i * 64 * KH)};
-    r.wave[1] = {ctcfa::kRoleLight, 4, (int16_t)(256 * KH)};
-    r.wave[3] = {ctcfa::kRoleLight, 5, (int16_t)(256 * KH + 64 * KL)};
-    r.wave[5] = {ctcfa::kRoleProducer, 0, 0};
-    r.wave[7] = {ctcfa::kRoleIdle, 0, 0};
-    return r;
-}
-
-// Six equal tiles on 8 waves: pairs (H,H), (H,producer), (H,H), (H,idle) -> with the neighbour
-// workgroup rotated by one SIMD every SIMD of the CU carries exactly 3 tiles (a 7-wave workgroup
-// leaves one SIMD with 4).
-ctcfa::FillRoles balanced8_roles(int K) {
-    ctcfa::FillRoles r{};
-    r.nwaves = 8;
-    r.nstages = 6;
-    r.cpad = 64 * K * 6;
-    const int tile_wave[6] = {0, 2, 4, 6, 1, 3};
-    for (int i = 0; i < 6; ++i) r.wave[tile_wave[i]] = {ctcfa::kRoleHeavy, (int8_t)i, (int16_t)(i * 64 * K)};
-    r.wave[5] = {ctcfa::kRoleProducer, 0, 0};
-    r.wave[7] = {ctcfa::kRoleIdle, 0, 0};
-    return r;
-}
-
-// Vocabularies staged row by row (32 < pitch <= 64, V != pitch): the eighth wave of the mixed
-// shape becomes a second producer, each stages every other row.
-void split_producer(ctcfa::FillRoles* r) {
-    r->wave[5] = {ctcfa::kRoleProducer, 0, 2};
-    r->wave[7] = {ctcfa::kRoleProducer, 1, 2};
 }
 
 const int kKs[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
 
-int lds_bytes_fill(int W, int VP) {
-    // emission ring (W+1 slots) + boundary rings + last-column ring + sink
-    return (W + 1) * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + (W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + ctcfa::kSinkBytes + 16;
+int waves_of(int W, int nprod) {
+    if (W + nprod <= 4) return 4;
+    if (W + nprod <= 8 && W <= 6) return 8;
+    return W + nprod;
+}
+
+int lds_bytes_fill(int NS, int W, int K, int VP) {
+    // emission ring (NS slots) + exchange rings + last-column ring + counters + sink
+    return NS * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + W * ctcfa::kGroups * NS * ctcfa::halo_lanes(K) * K * 4 +
+           64 * 4 + ctcfa::kFlagInts * 4 + ctcfa::kSinkBytes;
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
-// Launch-shape choice from a two-bound cost model of the fill kernel (constants
-// measured with tools/valu_rate.hip, checked against tools/shape_search.py):
-//   a row of a K-column tile costs its wave  n(K) = 9.5 K + 7 instructions;
-//   a wave issues at most one instruction per ~4.7 cycles            -> wave bound  4.7 n
-//   a SIMD retires ~one instruction per 2 cycles for this mix         -> SIMD bound  2 n x (tiles on the
-//                                                                        most loaded SIMD of a CU)
+// Launch-shape choice from a two-bound cost model of the fill kernel:
+//   a row of a K-column tile costs its wave  K gathers (LDS, ~12 cycles each for the issuing wave)
+//   + v K + 2 vector instructions (~4.4 cycles each), v = 3 in checkpoint mode, 9 with the decision math;
+//   a SIMD retires the same instructions at ~2.5 / ~3 cycles each           -> SIMD bound x tiles on the
+//                                                                               most loaded SIMD of a CU
 //   G workgroups share a CU (LDS, wave slots, VGPRs); a batch takes ceil(B / (G x CUs)) rounds.
-// `mixed` reports whether the 8-wave shape (4 heavy + 2 light tiles, 2 heavy + 1 light per SIMD)
-// beats five equal tiles.
-struct ShapeChoice { int K, W; bool mixed; bool balanced8 = false; };
+struct ShapeChoice { int K, W, NS; };
 
-int vgprs_of(int K) {  // compiled register counts, rounded up (allocation granule 8)
+int vgprs_of(int K) {  // compiled register counts (decision-word mode, the larger), rounded up to the allocation granule 8
     switch (K) {
-        case 1: case 2: return 72;
-        case 3: return 80;
-        case 4: return 88;
-        case 5: return 96;
-        case 6: return 104;
-        case 8: return 128;
-        case 10: return 168;
-        case 12: return 200;
+        case 1: case 2: return 64;
+        case 3: case 4: return 96;
+        case 5: return 112;
+        case 6: return 128;
+        case 8: return 160;
+        case 10: return 192;
+        case 12: return 224;
         default: return 256;
     }
 }
 
-bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_cu, int force_k, bool allow_mixed,
+bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_cu, int force_k, int nprod,
                 bool ckpt, ShapeChoice* out) {
     double best_cost = -1.0;
-    ShapeChoice best{0, 0, false};
+    ShapeChoice best{0, 0, 0};
     const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
-    // Wide pitches (65..128-entry vocabularies): their conflict-laden gathers need rows long enough
-    // to hide the LDS latency, and measured a second round of workgroups costs far more than the
-    // model says (V = 76: K=5 in one round 467 us, K=2 in two rounds 757 us).  First look only at
-    // shapes that hold the whole batch at once; fall back to everything if there is none.
-    bool single_round_only = VP > 64;
-    // per row of a K-column tile: 9.5 VALU per cell with the decision math, 3.5 in checkpoint mode
-    auto instr = [ckpt](int K) { return (ckpt ? 3.5 : 9.5) * K + 7.0; };
-    auto consider = [&](int K, int W, bool mixed, int stages, int waves_per_wg) {
-        const int lds = lds_bytes_fill(stages, VP);
-        if (lds > lds_limit) return;
+    int NS = 4;
+    if (const char* e = std::getenv("CTCFA_NS")) NS = std::max(2, std::min(8, std::atoi(e)));
+    const double v = ckpt ? 3.0 : 9.0;
+    for (int K : kKs) {
+        if (force_k && K != force_k) continue;
+        const int U = tile_useful_cols(K);
+        const int W = (Cmax + (K - 1) + U - 1) / U;   // (the left padding can take up to K-1 columns)
+        const int waves_per_wg = waves_of(W, nprod);
+        if (W > 16 - nprod || (K >= 10 && waves_per_wg > 5) || (K == 8 && waves_per_wg > 8)) continue;  // launch bounds: K >= 10: 320 threads, K == 8: 512
+        const int lds = lds_bytes_fill(NS, W, K, VP);
+        if (lds > lds_limit) continue;
         auto r512 = [](int x) { return (x + 511) / 512 * 512; };  // LDS is handed out in 512-byte units
         const int g_lds = std::max(lds_limit / r512(lds), 1);
         const int g_wave = 32 / waves_per_wg;
-        const int g_vgpr = 4 * (512 / vgprs_of(K)) / waves_per_wg;
+        const int g_vgpr = std::max(1, 4 * (512 / vgprs_of(K)) / std::min(waves_per_wg, W + nprod));
         int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
         // Pipelined schedule: the backtrack workgroups of the previous batch (lds_beside bytes each)
-        // run beside this fill.  When the whole batch is resident at once they only get in if the
-        // fill workgroups leave them room; if not, the two kernels take turns (V = 38 with seven ring
-        // slots: 0.38 ms per step instead of 0.28).  With several rounds of fill workgroups they slip
-        // in as those retire (B = 4096: K = 4, W = 3 at four per CU stays the best shape).
+        // run beside this fill; leave them room when the whole batch is resident at once.
         if (G >= wg_per_cu_needed && wg_per_cu_needed > 1 &&
             wg_per_cu_needed * r512(lds) + std::min(wg_per_cu_needed, 2) * r512(lds_beside) > lds_limit)
             G = wg_per_cu_needed - 1;
+        if (G < 1) G = 1;
         const int g_eff = std::min(G, wg_per_cu_needed);
         const int rounds = (wg_per_cu_needed + G - 1) / G;
-        if (single_round_only && rounds > 1) return;
-        const double wave_bound = 4.7 * instr(K);
-        double simd_bound;
-        if (mixed) {
-            if (g_eff < 2) return;  // the pairing needs two workgroups on a CU
-            simd_bound = 2.0 * (2.0 * instr(K) + instr(K / 2)) * (g_eff / 2.0);
-        } else {
-            // workgroups of 4k waves land evenly on the four SIMDs (the producers rotate); other
-            // sizes leave one SIMD with an extra wave: count the producers as tiles there
-            const double tiles = (waves_per_wg % 4 == 0) ? std::ceil(g_eff * W / 4.0)
-                                                         : std::ceil(g_eff * (W + 1) / 4.0);
-            simd_bound = 2.0 * instr(K) * tiles;
-        }
-        const double pad = (double)(64 * K * W) / (double)Cmax;  // only breaks ties: padding is inside W already
-        const double cost = rounds * std::max(wave_bound, simd_bound) * (1.0 + 1e-3 * pad) + 1e-3 * waves_per_wg;
+        const double wave_bound = 12.0 * K + 4.4 * (v * K + 2.0);
+        const double tiles = std::ceil(g_eff * W / 4.0);
+        const double simd_bound = tiles * (3.0 * K + 2.5 * (v * K + 2.0));
+        const double waste = (double)(W * 64 * K) / (double)Cmax;   // columns computed per label column
+        const double cost = rounds * std::max(wave_bound, simd_bound) * (1.0 + 1e-3 * waste) + 1e-3 * waves_per_wg;
         if (best_cost < 0.0 || cost < best_cost) {
             best_cost = cost;
-            best = {K, W, mixed, !mixed && W == 6 && waves_per_wg == 8};
-        }
-    };
-    for (int K : kKs) {
-        if (force_k && K != force_k) continue;
-        const int padded = roundup(Cmax, K);
-        const int W = (padded + 64 * K - 1) / (64 * K);
-        if (W > 15 || (K >= 10 && W > 4)) continue;  // +1 producer wave; K >= 10 kernels: <= 320 threads
-        consider(K, W, false, W, W + 1);
-        if (!force_k && allow_mixed && W == 5 && (K == 2 || K == 4)) consider(K, W, true, 6, 8);
-        if (!force_k && allow_mixed && W == 6) consider(K, W, false, 6, 8);  // six equal tiles on 8 waves
-    }
-    if (!best.K && single_round_only) {
-        single_round_only = false;
-        for (int K : kKs) {
-            if (force_k && K != force_k) continue;
-            const int padded = roundup(Cmax, K);
-            const int W = (padded + 64 * K - 1) / (64 * K);
-            if (W > 15 || (K >= 10 && W > 4)) continue;
-            consider(K, W, false, W, W + 1);
+            best = {K, W, NS};
         }
     }
     if (!best.K) return false;
@@ -322,6 +277,8 @@ const char* ctcfa_status_string(int s) {
         case CTCFA_ST_AUDIO_SHORTER_THAN_TEXT: return "Audio is shorter than text!";
         case CTCFA_ST_BACKTRACK_FAILED: return "backtrack left the trellis (IndexError in ctc_segmentation)";
         case CTCFA_ST_WINDOWED_UNSUPPORTED: return "windowed DP regime (T > min_window_size) with T beyond the LDS column buffer (~40 000 frames)";
+        case CTCFA_ST_TEXT_TOO_LONG: return "more label columns than one workgroup of the fill kernel covers";
+        case CTCFA_ST_INTERNAL: return "internal error: a wave of the fill kernel gave up waiting for a progress counter";
         default: return "unknown status";
     }
 }
@@ -451,24 +408,45 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
            : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
     pl->have_utt = (U != nullptr);
 
-    int Cmax = 2, Tmax = 1;
     for (int b = 0; b < batch; ++b) {
         if (T[b] < 1 || C[b] < 2 || (U && U[b] < 0)) {
             delete pl;
             return set_err(eng, CTCFA_ERR_INVALID, "need T >= 1, C >= 2 ([-1, ..., blank]) and U >= 0");
         }
-        Cmax = std::max(Cmax, (int)C[b]);
-        Tmax = std::max(Tmax, (int)T[b]);
     }
     pl->gather = gather;
+    const int nprod = 1;
+    // What the shapes alone decide, per segment (the package's assertion and window rule): only the
+    // segments that go through the fill kernel count for its launch shape -- one over-long text in a
+    // batch is that segment's status, not the batch's failure.
+    const int64_t lds_dyn_max = (int64_t)eng->lds_limit - 64;  // the windowed kernel also has a few static words
+    int c_limit = 0;   // label columns the widest fill shape can take
+    if (gather) c_limit = 15 * 64 + 1;
+    else
+        for (int K : kKs) {
+            const int wmax = K >= 10 ? 4 : K == 8 ? 8 - nprod : 16 - nprod;
+            for (int W = wmax; W >= 1; --W)
+                if (lds_bytes_fill(4, W, K, pl->VP) <= eng->lds_limit) {
+                    c_limit = std::max(c_limit, W * tile_useful_cols(K) - (K - 1));
+                    break;
+                }
+        }
+    std::vector<int32_t> pre(batch, CTCFA_ST_OK);
+    int Cmax = 2, Tmax = 1;
+    for (int b = 0; b < batch; ++b) {
+        if (C[b] > T[b]) pre[b] = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
+        else if (T[b] > params->min_window_size)
+            pre[b] = ((int64_t)T[b] * 4 > lds_dyn_max) ? CTCFA_ST_WINDOWED_UNSUPPORTED : ctcfa::kPreWindowed;
+        else if (C[b] > c_limit) pre[b] = CTCFA_ST_TEXT_TOO_LONG;
+        if (pre[b] == CTCFA_ST_OK) {
+            Cmax = std::max(Cmax, (int)C[b]);
+            Tmax = std::max(Tmax, (int)T[b]);
+        }
+    }
     // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
-    // of decision words (3.5 instead of 9.5 VALU per cell) and the backtrack recomputes the decisions
+    // of decision words (3 instead of 9 VALU per cell) and the backtrack recomputes the decisions
     // along the path -- a longer, serial backtrack.  It pays where the fill is what a batch waits
-    // for: many label columns per segment, or enough segments per CU (profiles/r01_modes.txt, pipelined
-    // schedule, segments x columns: +11 % at 512 x 640, +35 % at 512 x 1242, +50 % at 4096 x 640,
-    // +11..31 % at 1024..1536 x 254; 0 at 512 x 512, -1..-5 % at 512 x 128..380, -12 % at 2048 x 128,
-    // -39 % for 4096 word-level rows of ~425 frames x 54 columns, where the backtracks are the longer
-    // kernel in either mode).
+    // for: many label columns per segment, or enough segments per CU.
     // CTCFA_CHECKPOINT=1 / CTCFA_DECISION_BITS=1 force one mode (tests, tuning).
     {
         const bool can = !gather && pl->VP <= 64;
@@ -481,56 +459,44 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
     int bt_lds_estimate;
     {
-        const int Tb = std::min(Tmax, std::max(1, (int)params->min_window_size));  // longer segments: windowed kernel
+        const int Tb = Tmax;
         const int rec = ((Tb + ctcfa::kRows - 1) / ctcfa::kRows * 8 + 15) / 16 * 16;
         const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8 + 256;
         bt_lds_estimate = pl->ckpt ? rec + (Cmax + 15) / 16 * 16 + std::max(Tb * 4, ring) : rec + Tb * 4;
     }
-    ShapeChoice shape{0, 0, false};
+    ShapeChoice shape{0, 0, 0};
     if (gather) {
         const int W = std::max(1, (Cmax - 1 + 63) / 64);  // label columns 1 .. C-1, one per lane
-        if (W > 15) {
+        shape = {1, W, 0};
+        pl->roles = ctcfa::FillRoles{};
+        pl->roles.nwaves = W;   // W compute waves, no producer
+        pl->roles.nstages = W;
+        pl->roles.cpad = 64 * W;
+    } else {
+        if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, bt_lds_estimate, eng->num_cu, force_k, nprod, pl->ckpt,
+                        &shape)) {
             delete pl;
-            return set_err(eng, CTCFA_ERR_UNSUPPORTED, "vocab > 128: at most 961 label columns per segment");
+            return set_err(eng, force_k ? CTCFA_ERR_INVALID : CTCFA_ERR_UNSUPPORTED,
+                           force_k ? "cols_per_lane: not a compiled tile width, or too narrow for this batch"
+                                   : "no launch shape fits");
         }
-        shape = {1, W, false};
-    } else if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, bt_lds_estimate, eng->num_cu, force_k,
-                           !std::getenv("CTCFA_NO_MIXED"), pl->ckpt, &shape)) {
-        delete pl;
-        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "no launch shape fits (label sequence too long for one workgroup)");
+        pl->roles = tile_roles(shape.K, shape.W, shape.NS, nprod);
     }
     pl->K = shape.K;
     pl->W = shape.W;
-    pl->KL = shape.mixed ? shape.K / 2 : shape.K;
-    pl->roles = shape.mixed ? mixed8_roles(pl->K, pl->KL)
-                            : (shape.balanced8 ? balanced8_roles(pl->K) : uniform_roles(pl->K, pl->W));
-    if (shape.mixed && pl->VP > 32 && pl->VP <= 64 && vocab != pl->VP) split_producer(&pl->roles);
-    if (gather) {  // W compute waves, no producer
-        pl->roles.nwaves = pl->W;
-        pl->roles.wave[pl->W] = {ctcfa::kRoleIdle, 0, 0};
-    }
-    pl->fill_fn = select_fill(pl->K, pl->KL, pl->VP, pl->ckpt);
-    if (!pl->fill_fn) {
-        delete pl;
-        return set_err(eng, CTCFA_ERR_INVALID, "unsupported cols_per_lane");
+    if (!gather) {
+        pl->fill_fn = select_fill(pl->K, pl->VP, pl->ckpt);
+        if (!pl->fill_fn) {
+            delete pl;
+            return set_err(eng, CTCFA_ERR_INVALID, "unsupported cols_per_lane");
+        }
     }
     const int K = pl->K;
     const int64_t Cpad = pl->roles.cpad;
     pl->lds_fill = gather ? (pl->W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + ctcfa::kSinkBytes
-                          : lds_bytes_fill(pl->roles.nstages, pl->VP);
-    // tile that holds padded column pc
-    auto tile_of = [&](int pc, int* tk, int* tbase, int* tstage) {
-        for (int w = 0; w < pl->roles.nwaves; ++w) {
-            const ctcfa::WaveRole& r = pl->roles.wave[w];
-            if (r.role != ctcfa::kRoleHeavy && r.role != ctcfa::kRoleLight) continue;
-            const int k = r.role == ctcfa::kRoleHeavy ? pl->K : pl->KL;
-            if (pc >= r.cbase && pc < r.cbase + 64 * k) {
-                *tk = k; *tbase = r.cbase; *tstage = r.stage;
-                return true;
-            }
-        }
-        return false;
-    };
+                          : lds_bytes_fill(shape.NS, pl->W, K, pl->VP);
+    const int tileU = gather ? 64 : tile_useful_cols(K);
+    const int tileHL = gather ? 0 : ctcfa::halo_lanes(K);
     pl->segs.resize(batch);
     int64_t lpz_off = 0, lab_off = 0, frm_off = 0, utt_off = 0, bits_off = 0;
     for (int b = 0; b < batch; ++b) {
@@ -548,22 +514,16 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             s.owner_stage = (C[b] - 2) / 64;
             s.owner_lane = (C[b] - 2) % 64;
         } else {   // left padding: the last label column must sit at k == K-1 of its lane
-            int tk = K, tbase = 0, tstage = 0;
-            (void)tile_of(C[b] - 1, &tk, &tbase, &tstage);
-            s.shift = (tk - 1) - ((C[b] - 1 - tbase) % tk);   // stays inside the same lane, hence the same tile
-            s.owner_stage = tstage;
-            s.owner_lane = (C[b] - 1 + s.shift - tbase) / tk;
+            s.shift = ((K - 1) - (C[b] - 1) % K + K) % K;
+            const int pcl = C[b] - 1 + s.shift;   // padded column of the last label column
+            s.owner_stage = pcl / tileU;
+            s.owner_lane = tileHL + (pcl % tileU) / K;
         }
         s.seg_index = b;
-        s.prestatus = CTCFA_ST_OK;
-        if (C[b] > T[b]) s.prestatus = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
-        else if (T[b] > params->min_window_size) {
-            // windowed regime: own kernel, needs T floats of LDS and a T x C fp32 table in HBM
-            const int64_t lds_dyn_max = (int64_t)eng->lds_limit - 64;  // the kernel also has a few static words
-            if ((int64_t)T[b] * 4 > lds_dyn_max) {
-                s.prestatus = CTCFA_ST_WINDOWED_UNSUPPORTED;
-            } else {
-                s.prestatus = ctcfa::kPreWindowed;
+        s.prestatus = pre[b];
+        {
+            if (s.prestatus == ctcfa::kPreWindowed) {
+                // windowed regime: own kernel, needs T floats of LDS and a T x C fp32 table in HBM
                 s.win_off = pl->win_table_floats;
                 s.wcol_off = pl->win_cols;
                 pl->win_table_floats += (int64_t)T[b] * C[b];
@@ -642,7 +602,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
         PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
     }
-    if (pl->lds_fill > 48 * 1024)
+    if (pl->lds_fill > 48 * 1024 && pl->fill_fn)
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
     if (pl->lds_bt > 48 * 1024)
@@ -768,7 +728,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.lab_bytes = pl->lab_bytes;
     bp.dur = pl->prm.index_duration;
     const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
-                           pl->d_lastcol[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
+                           pl->d_lastcol[ws], pl->gather ? nullptr : &pl->d_roles->spin_timeout, bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
                            want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<0>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,

@@ -39,6 +39,12 @@
 //     the -1e9 zone above the diagonal while every emission so far is <= 0).
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef CTCFA_PRODUCER_PRIO
+#define CTCFA_PRODUCER_PRIO 0
+#endif
+#ifndef CTCFA_TILE_PRIO
+#define CTCFA_TILE_PRIO 4
+#endif
 #ifndef CTCFA_PF
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
 #endif
@@ -72,27 +78,55 @@ struct SegDesc {
     int64_t wcol_off;     // windowed segments: ints into the per-column offsets workspace
 };
 
-// Launch shape of the fill kernel: what each wave of a workgroup does.  Tiles ("stages") are
-// numbered left to right; stage l works one 32-row block behind stage l-1.  A heavy tile has
-// 64*KH columns, a light one 64*KL.
-enum : int8_t { kRoleIdle = 0, kRoleProducer = 1, kRoleHeavy = 2, kRoleLight = 3 };
+// Launch shape of the fill kernel: what each wave of a workgroup does.  Tiles are numbered left
+// to right; a tile is one wave, lane l owns K consecutive padded columns.  The first HL lanes of a
+// tile are its HALO: copies of the last HL*K columns of the tile to its left.
+enum : int8_t { kRoleIdle = 0, kRoleProducer = 1, kRoleTile = 2 };
 struct WaveRole {
     int8_t role;
-    int8_t stage;
-    int16_t cbase;   // first padded column of the tile
+    int8_t stage;    // tile index (tiles), or the share of the rows a producer stages
+    int16_t cbase;   // padded column of lane 0, k = 0 (tile 0: negative, its halo is left padding)
 };
 struct FillRoles {
     int32_t nwaves;   // waves per workgroup (blockDim.x / 64)
-    int32_t nstages;  // compute tiles
-    int32_t cpad;     // padded columns = sum of tile widths (row pitch of the decision words)
-    int32_t reserved;
+    int32_t nstages;  // compute tiles W
+    int32_t cpad;     // padded columns = W * (64 - HL) * K (row pitch of the trace words)
+    int32_t nslots;   // emission ring slots NS (32-row blocks)
+    int32_t nprod;    // producer waves (1, or 2: each stages every other row)
+    int32_t reserved[3];
     WaveRole wave[16];
+    // device copy only: set by a wave whose wait on a progress counter gave up (a lost counter would
+    // otherwise hang the GPU); the backtrack kernel turns it into status CTCFA_ST_INTERNAL for the batch
+    int32_t spin_timeout;
+    int32_t pad[3];
 };
+
+constexpr int kHaloRows = 16;       // rows between two refreshes of a tile's halo (a "group")
+constexpr int kGroups = kRows / kHaloRows;
+constexpr int kPollLead = 4;        // a tile asks for its neighbour's group this many rows before it needs it
+constexpr int kPeekLead = 3;        // ... and reads the counter this many rows before it looks at the value
+constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, pad
+constexpr int kBigCount = 0x3fffffff;
+constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a lost counter must not hang the GPU
+#ifdef CTCFA_DEBUG_SPIN
+#define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) printf("fill spin timeout: %s wg %d a %d b %d c %d T %d C %d\n", what, (int)blockIdx.x, (int)(a), (int)(b), (int)(c), T, C); } while (0)
+#else
+#define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) atomicOr(const_cast<int32_t*>(&roles->spin_timeout), 1); } while (0)
+#endif
+
+using lds_vint = volatile __attribute__((address_space(3))) int;   // counters in LDS
+
+__host__ __device__ constexpr int halo_lanes(int K) { return (kHaloRows + K - 1) / K; }
 
 __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) {
     // lane i <- src[lane i-1]; lane 0 keeps `old_lane0` (bound_ctrl off)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_lane0),
                                                       __float_as_int(src), 0x138, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float dpp_wave_shr1_zero(float src) {
+    // lane i <- src[lane i-1]; lane 0 <- 0 (bound_ctrl: the DPP folds into the consuming VALU op)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x138, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ void lds_barrier() {
@@ -108,23 +142,30 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Fill kernel.  grid = B workgroups (one per segment), block = 64*nwaves threads; the role
-// table says which wave computes which tile ("stage"), which one is the producer (stages
-// emission rows global -> (e, m) pairs in the LDS ring) and which ones leave at once.
-// Uniform shapes: waves 0..W-1 are stages 0..W-1 with K columns per lane, wave W the producer.
-// Mixed shape (KH, KL), 8 waves: a workgroup of 8 waves lands as {w, w+4} pairs on the four
-// SIMDs and the neighbour workgroup on the same CU is rotated by one SIMD, so giving pairs
-// (heavy, heavy), (light, producer), (heavy, heavy), (light, idle) puts exactly
-// 2 heavy + 1 light tile on every SIMD (measured with tools/hwid_probe.hip): a step costs what
-// the most loaded SIMD issues, and 5 equal tiles per workgroup would put 3 on two SIMDs and 2
-// on the others.
-// Roles never mix: compute waves issue only global STORES (decision words, last-column
-// scores) and never wait on vmcnt; the producer issues only LOADS.  (vmcnt retires in issue
-// order on gfx9, so one wave doing both pays an HBM write round trip in every load wait.)
-// dynamic LDS = (W+1) slots * kRows * (VP+1) * 8  +  boundary columns  +  small buffers.
+// Fill kernel.  grid = B workgroups (one per segment), block = 64 * nwaves threads; the role
+// table says which wave computes which tile, which ones are producers (stage emission rows
+// global -> (e, m) pairs in the LDS ring) and which ones leave at once.
+//
+// Tiles do NOT hand a boundary column to each other row by row.  Column c at row t depends on
+// columns c-r .. c of row t-r only, so a tile that also carries the HL*K >= 16 columns to its left
+// (its halo lanes) can run 16 rows on its own: row r of a group is wrong in the first r halo
+// columns and right everywhere else.  Every 16 rows (a "group") the halo lanes are refreshed from
+// what the left neighbour published at the end of the same group -- ONE small LDS exchange per 16
+// rows instead of a ds_read/ds_write per row, no pipeline skew between tiles (all of them work on
+// the same 32-row block: the emission ring is NS = 4 slots whatever the tile count) and no
+// workgroup barrier in the steady state: progress counters in LDS (done[w] = groups tile w has
+// finished, staged[p] = blocks producer p has staged) are all the waves wait on --
+//   tile w, kPollLead rows before the end of group g:   done[w-1] >= g + 1   (w > 0)
+//   tile w, before block j:                             staged[*] >  j
+//   producer, before it overwrites the slot of block j: done[*]   >= 2 (j - NS + 1)
+// LDS operations of one wave execute in order, so "data, then counter" needs no wait in between.
+// Roles never mix: compute waves issue only global STORES (trace words, last-column scores) and
+// never wait on vmcnt; producers issue only LOADS.
+// dynamic LDS = NS slots * kRows * (VP+2) * 8  +  exchange rings  +  last-column ring + counters.
 // ---------------------------------------------------------------------------------------
-template <int KH, int KL, int VP, bool CK = false>
-__global__ void __launch_bounds__((KH >= 10) ? 320 : 1024)
+template <int K, int VP, bool CK = false>
+__global__ void __attribute__((amdgpu_waves_per_eu(K <= 2 ? 8 : 1)))   // K <= 2: 64 VGPRs, room for the backtrack beside it
+__launch_bounds__((K >= 10) ? 320 : (K >= 8) ? 512 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int preamble,
@@ -132,14 +173,17 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int PITCH = VP + kPitchPad;  // row pitch in (e, m) entries; entry VP = start-column pseudo label
     constexpr int SLOT_BYTES = kRows * PITCH * 8;
+    constexpr int HL = halo_lanes(K);      // halo lanes of a tile
+    constexpr int XW = HL * K;             // floats per exchange row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WaveRole my = roles->wave[wave_id];
-    const int W = roles->nstages;         // compute tiles == pipeline stages
-    const int NS = W + 1;                 // ring slots: W blocks being read + 1 being written
-    const int w = my.stage;               // this wave's stage (compute waves)
+    const int W = roles->nstages;         // compute tiles
+    const int NS = roles->nslots;         // emission ring slots
+    const int XR = kGroups * NS;          // exchange ring: groups a tile can be ahead of its right neighbour
+    const int w = my.stage;               // this wave's tile (compute waves)
 
     const SegDesc sd = segs[blockIdx.x];
     if (sd.prestatus != 0) return;  // uniform: nothing to fill
@@ -149,38 +193,78 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
 
     // LDS after the emission ring:
-    //   bnd    [(W+1)][128] floats  boundary columns: ring w, index t % 128 = last column of wave w-1 at row t
-    //   lcring [64] floats          last label column (owner wave), index t % 64
-    //   sink   1280 B               target of the lanes that publish nothing
-    const uint32_t bnd_base = static_cast<uint32_t>(NS * SLOT_BYTES);
-    const uint32_t lcring_base = bnd_base + static_cast<uint32_t>((W + 1) * kBndPitch * 4);
-    const uint32_t sink_base = lcring_base + 64 * 4;
-    // posflag (last 4 bytes of the sink area's tail): set by the producer as soon as any staged
-    // emission is not <= 0 -- from then on nobody may assume that unreachable cells are -1e9
-    volatile int* posflag = reinterpret_cast<volatile int*>(smem + sink_base + kSinkBytes);
-    float* bnd = reinterpret_cast<float*>(smem + bnd_base);
+    //   xch    [W][XR][XW] floats  exchange rows: tile w's last XW columns at the end of group g in [w][g % XR]
+    //   lcring [64] floats         last label column (owner tile), index t % 64
+    //   flags  [32] ints           done[0..15], staged[16..17], posflag [18]
+    //   sink   1 KB                target of the owner tile's lanes that publish nothing
+    const uint32_t xch_base = static_cast<uint32_t>(NS * SLOT_BYTES);
+    const uint32_t lcring_base = xch_base + static_cast<uint32_t>(W * XR * XW * 4);
+    const uint32_t flag_base = lcring_base + 64 * 4;
+    const uint32_t sink_base = flag_base + kFlagInts * 4;
+    // (an explicit LDS pointer: a volatile access through a generic pointer compiles to flat_load +
+    // s_waitcnt vmcnt(0), which would make the tiles wait for their own trace stores)
+    lds_vint* flags = (lds_vint*)(smem + flag_base);
+    // posflag: set by a producer as soon as any staged emission is not <= 0 -- from then on nobody
+    // may assume that unreachable cells are -1e9
+    lds_vint* posflag = flags + 18;
     const int nblk = (T - 1 + kRows - 1) / kRows;
     const int Cpad = roles->cpad;
-    const int nsteps = nblk + W - 1;
 
-    for (int i = tid; i < (W + 1) * kBndPitch; i += blockDim.x) bnd[i] = kProbMax;
-    if (tid == 0) *posflag = 0;  // producers raise it only after the first barrier, nobody reads it before the second
-
-    if (my.role == kRoleIdle) {
-        lds_barrier();  // its share of the ring initialisation is visible; from here on a
-        return;         // finished wave no longer counts at s_barrier
+    {
+        float* xch = reinterpret_cast<float*>(smem + xch_base);
+        for (int i = tid; i < W * XR * XW; i += blockDim.x) xch[i] = kProbMax;
+        if (tid < kFlagInts) flags[tid] = (tid == 17 && roles->nprod < 2) ? kBigCount : 0;
     }
+    lds_barrier();  // the only workgroup barrier: everything after it is counter-paced
+    if (my.role == kRoleIdle) return;
+
     if (my.role == kRoleProducer) {
         // ============================ producer wave ===========================================
-        // Block jb = rows t in [32*jb + 1, 32*jb + 32].  One pass of the wave covers 64/VP rows
-        // (VP <= 64) or half a row (VP == 128).  Loads run TWO blocks ahead of the compute
-        // waves (registers double-buffered), so HBM latency never sits inside a step.
+        // Block jb = rows t in [32*jb + 1, 32*jb + 32] -> ring slot jb % NS.  Loads run a block
+        // ahead of the LDS writes (registers), the writes up to NS - 1 blocks ahead of the tiles.
+        // Little work (~5 % of a SIMD's issue slots) but everybody's critical path: without priority the
+        // tiles on its SIMD starve it and the whole workgroup runs at the producer's pace.
+        __builtin_amdgcn_s_setprio(CTCFA_PRODUCER_PRIO);
+        const int part = my.stage;  // which share of the rows (nprod == 2), and which staged[] counter
         constexpr int PASSES = kRows * VP / 64;
         constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
         bool notneg = false;  // any staged emission that is not <= 0 (NaN counts)
-        auto publish_flag = [&]() {
+#ifdef CTCFA_STAMP
+        unsigned long long pst_space = 0, pst_t0 = __builtin_amdgcn_s_memtime(), pst_w0 = 0, pst_write = 0;
+        int pst_n = 0;
+#endif
+        auto wait_space = [&](int jb) {   // every tile is done with the block that slot jb % NS still holds
+#ifdef CTCFA_STAMP
+            pst_w0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (jb < NS) return;
+            const int need = kGroups * (jb - NS + 1);
+            const int idx = lane < W ? lane : 0;
+            int spins = 0;
+            while (__builtin_amdgcn_ballot_w64(flags[idx] < need) != 0ull) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kSpinCap) { CTCFA_SPIN_DIAG("producer", jb, need, (int)flags[idx]); break; }
+            }
+            asm volatile("" ::: "memory");
+#ifdef CTCFA_STAMP
+            pst_space += __builtin_amdgcn_s_memtime() - pst_w0;
+            pst_n += spins > 0;
+            pst_w0 = __builtin_amdgcn_s_memtime();
+#endif
+        };
+        auto publish = [&](int jb) {
             if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
+            asm volatile("" ::: "memory");  // data and posflag first, then the counter (LDS executes a wave's operations in order)
+            if (lane == 0) flags[16 + part] = jb + 1;
+#ifdef CTCFA_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pst_write += __builtin_amdgcn_s_memtime() - pst_w0;
+            if (jb == nblk - 1 && lane == 0 && blockIdx.x < 64) {
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(lastcol) + (blockIdx.x * 16 + 15) * 8;
+                o[0] = __builtin_amdgcn_s_memtime() - pst_t0; o[1] = pst_space; o[2] = pst_write; o[3] = pst_n; o[4] = nblk;
+            }
+#endif
         };
         auto load_chunk = [&](int jb, int p0, float (&e)[CH]) {
             const int t0 = jb * kRows + 1;
@@ -262,24 +346,22 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     unsigned char* q = smem + ent + p * (RPP * PITCH * 8);
                     *reinterpret_cast<float4*>(q) = lo;
                     *reinterpret_cast<float4*>(q + 16) = hi;
-                    // sink offsets stay inside the 2 KB sink: p * RPP * PITCH * 8 would not
+                    // sink offsets stay inside the 1 KB sink: p * RPP * PITCH * 8 would not
                     *reinterpret_cast<float2*>(smem + spc + ((lv == 0) ? p * (RPP * PITCH * 8) : 0)) = sp;
                 }
             };
             float4 ea[NP], eb[NP];
             vload(0, ea);
-            vwrite(0, ea);
-            if (1 < nblk) vload(1, ea);
-            lds_barrier();
-            publish_flag();
-            for (int s = 0; s < nsteps; s += 2) {
-                if (s + 2 < nblk) vload(s + 2, eb);
-                if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
-                lds_barrier();
-                if (s + 1 >= nsteps) break;
-                if (s + 3 < nblk) vload(s + 3, ea);
-                if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }
-                lds_barrier();
+            for (int jb = 0; jb < nblk; jb += 2) {
+                if (jb + 1 < nblk) vload(jb + 1, eb);
+                wait_space(jb);
+                vwrite(jb, ea);
+                publish(jb);
+                if (jb + 1 >= nblk) break;
+                if (jb + 2 < nblk) vload(jb + 2, ea);
+                wait_space(jb + 1);
+                vwrite(jb + 1, eb);
+                publish(jb + 1);
             }
         } else if constexpr (VP > 32 && VP <= 64) {
             // ---- one row per pass (character vocabularies between 33 and 64 entries that are not
@@ -291,10 +373,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int svl = lane < V ? lane : V - 1;             // lanes past the vocabulary re-read its last entry
             // LDS entry a lane writes: its own, the pseudo entry VP, or (lanes past VP) the pad entry VP+1
             const uint32_t ent = static_cast<uint32_t>((lane == kPseudoLane ? VP : (lane <= VP ? lane : VP + 1)) * 8);
-            // The role entry of a producer says which share of the rows it stages: part `stage` of
-            // `cbase` parts (the mixed shape makes its otherwise idle eighth wave a second producer,
-            // on the other lightly loaded SIMD).
-            const int part = my.stage;
+            // With two producers (roles->nprod == 2) each stages every other row of a block and
+            // counts its blocks in its own staged[] entry.
             auto run = [&](auto parts_tag) {
                 constexpr int PARTS = decltype(parts_tag)::value;
                 constexpr int NR = kRows / PARTS;  // rows of a block this wave stages: part, part + PARTS, ..
@@ -323,40 +403,30 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
                     }
                 };
-                // One register set: the loads of block s+2 are issued right after block s+1 has been
-                // written and have a whole step (~3 us) to arrive.  (A second set would cost 32 VGPRs
-                // of every wave of the kernel, i.e. the room the overlapped backtrack kernel lives in.)
+                // One register set: the loads of block jb+1 are issued right after block jb has been written.
                 float ea[NR];
                 rload(0, ea);
-                rwrite(0, ea);
-                if (1 < nblk) rload(1, ea);
-                lds_barrier();
-                publish_flag();
-                for (int s = 0; s < nsteps; ++s) {
-                    if (s + 1 < nblk) { rwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
-                    if (s + 2 < nblk) rload(s + 2, ea);
-                    lds_barrier();
+                for (int jb = 0; jb < nblk; ++jb) {
+                    wait_space(jb);
+                    rwrite(jb, ea);
+                    publish(jb);
+                    if (jb + 1 < nblk) rload(jb + 1, ea);
                 }
             };
-            if (my.cbase == 2) run(std::integral_constant<int, 2>{});
+            if (roles->nprod == 2) run(std::integral_constant<int, 2>{});
             else run(std::integral_constant<int, 1>{});
         } else if constexpr (PASSES == CH) {
-
-            // whole block in one chunk (VP == 32): two register sets, swapped by 2x unrolling
-            float ea[CH], eb[CH];
+            // whole block in one chunk (VP == 32, V < 32).  One register set: the loads of block jb+1 are
+            // issued right after block jb has been written (the ring keeps the tiles fed meanwhile; a
+            // second set would cost every wave of the kernel 16 VGPRs and with them the 64-register
+            // budget that lets two backtrack workgroups sit beside two fill workgroups on a CU)
+            float ea[CH];
             load_chunk(0, 0, ea);
-            write_chunk(0, 0, ea);
-            if (1 < nblk) load_chunk(1, 0, ea);
-            lds_barrier();
-            publish_flag();
-            for (int s = 0; s < nsteps; s += 2) {
-                if (s + 2 < nblk) load_chunk(s + 2, 0, eb);
-                if (s + 1 < nblk) { write_chunk(s + 1, 0, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
-                lds_barrier();
-                if (s + 1 >= nsteps) break;
-                if (s + 3 < nblk) load_chunk(s + 3, 0, ea);
-                if (s + 2 < nblk) { write_chunk(s + 2, 0, eb); publish_flag(); }
-                lds_barrier();
+            for (int jb = 0; jb < nblk; ++jb) {
+                wait_space(jb);
+                write_chunk(jb, 0, ea);
+                publish(jb);
+                if (jb + 1 < nblk) load_chunk(jb + 1, 0, ea);
             }
         } else if constexpr (VP > 64) {
             // ---- character vocabularies between 65 and 128 entries (e.g. 76 for French): a row per
@@ -404,24 +474,20 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             };
             float ea[kRows], eb[kRows];
             wload(0, ea, eb);
-            wwrite(0, ea, eb);
-            if (1 < nblk) wload(1, ea, eb);
-            lds_barrier();
-            publish_flag();
-            for (int s = 0; s < nsteps; ++s) {
-                if (s + 1 < nblk) { wwrite(s + 1, ea, eb); publish_flag(); }  // slot (s+1) % NS was last read in step s-1
-                if (s + 2 < nblk) wload(s + 2, ea, eb);
-                lds_barrier();
+            for (int jb = 0; jb < nblk; ++jb) {
+                wait_space(jb);
+                wwrite(jb, ea, eb);
+                publish(jb);
+                if (jb + 1 < nblk) wload(jb + 1, ea, eb);
             }
         }
         return;
     }
 
-    // ================================ compute waves ===========================================
-    auto compute = [&](auto ktag) {
-    constexpr int K = decltype(ktag)::value;
+    // ================================ compute tiles ============================================
     const int cbase = my.cbase;
     float prev[K];
+    float hx[K];        // halo values to put in at the start of the next group
     uint32_t dec[K];
     uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair in row 0 of the current slot
 #pragma unroll
@@ -434,44 +500,66 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         else lab = blank;                      // right padding: any valid entry
         gaddr[k] = static_cast<uint32_t>(lab) * 8u;
         prev[k] = (c <= 0) ? 0.0f : kProbMax;  // table[0,0] = 0, table[0,c>0] = -1e9
+        hx[k] = prev[k];
         dec[k] = 0u;
     }
-    const int wstar = sd.owner_stage;  // stage that owns the last label column (ragged batches: <= W-1)
+    const bool is_halo = (w > 0) && (lane < HL);   // tile 0's first lanes are left padding: they reproduce table[t,0] themselves
+    const int wstar = sd.owner_stage;  // tile that owns the last label column (ragged batches: <= W-1)
     const int lstar = sd.owner_lane;
     float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);  // .x = row 0 of every label column
+    // exchange rows: what I read (left neighbour's ring; lanes past the halo re-read its last entry) and
+    // what I publish (my last HL lanes)
+    const uint32_t xin_addr = xch_base + static_cast<uint32_t>(((w > 0 ? w - 1 : 0) * XR * XW + (lane < HL ? lane : HL - 1) * K) * 4);
+    const uint32_t xout_addr = xch_base + static_cast<uint32_t>((w * XR * XW + (lane >= 64 - HL ? lane - (64 - HL) : 0) * K) * 4);
+    const bool publishes = lane >= 64 - HL;
 
-    lds_barrier();  // block 0 staged, boundary columns initialised
-    // Three waves share a SIMD and VALU/LDS arbitration goes by priority, then age: the
-    // later-dispatched waves would always lose and every step ends at a barrier that waits for
-    // them.  Static priorities (younger half above older half, both above the light producer)
-    // even the waves out: -4 % kernel time.
-    // In the mixed shape the heavy tiles are the critical ones (the light tiles wait for them at
-    // every barrier anyway): priority by weight there (-4 % again).
-    if (KH != KL ? (my.role == kRoleHeavy) : (w >= (W + 1) / 2)) __builtin_amdgcn_s_setprio(2);
+    // Tiles of one SIMD compete for issue slots by priority, then age: the later-dispatched waves
+    // would always lose.  A tile is only ever waited for by its right neighbour, so the left ones go first.
+#if CTCFA_TILE_PRIO == 1
+    if (w < (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(1);
+#elif CTCFA_TILE_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#elif CTCFA_TILE_PRIO == 3
+    __builtin_amdgcn_s_setprio(2);
+#elif CTCFA_TILE_PRIO == 4   // later tiles first
+    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+#elif CTCFA_TILE_PRIO == 5 || CTCFA_TILE_PRIO == 6  // graduated: the further right, the higher
+    {
+        const int pr = W > 1 ? (w * 4) / W : 0;
+        if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+#elif CTCFA_TILE_PRIO == 7  // later half 3, earlier half 1
+    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(1);
+#endif
 
     // Dead zone: column c cannot reach the end cell's column C-1 from rows t > T-C+c, so the
-    // backtrack never visits those cells and they feed only other dead cells.  A wave stops
-    // after the last block in which its right-most label column is still alive (exact for any
-    // input: nothing downstream reads what is skipped; later waves only read boundary rows that
-    // are alive, or compute dead cells from stale-but-finite ring entries).
+    // backtrack never visits those cells and they feed only other dead cells (in this tile or, through
+    // the exchange rows, in the halo of the next one).  A tile stops after the last block in which
+    // its right-most column is still alive (exact for any input).
     int jlast = nblk - 1;
     {
-        const int cmax = (cbase + 64 * K - 1) - shift;     // right-most column of this wave
+        const int cmax = (cbase + 64 * K - 1) - shift;     // right-most column of this tile
         if (cmax < C - 1) {
             const int tdead = T - C + cmax;                // last row where cmax is alive
             jlast = tdead >= 1 ? (tdead - 1) / kRows : -1;
             if (jlast > nblk - 1) jlast = nblk - 1;
         }
     }
-    if (w > wstar) jlast = -1;  // ragged batch: this wave holds right padding only
+    if (w > wstar) jlast = -1;  // ragged batch: this tile holds right padding only
     // Unreachable zone: cells with c > t hold exactly -1e9 as long as every emission so far is
-    // <= 0 (log-probabilities always are; the producer's posflag says when they are not).  A wave
-    // whose left-most column is cmin idles through the blocks that end before row cmin and then
-    // starts from the state it would have computed: -1e9 in every column, -1e9 boundary rows.
+    // <= 0 (log-probabilities always are; the producers' posflag says when they are not).  A tile
+    // whose left-most column (halo included) is cmin idles through the blocks that end before row
+    // cmin and then starts from the state it would have computed: -1e9 in every column.  Its exchange
+    // rows still hold the -1e9 they were initialised with, so it only counts the groups.
     int jfirst = 0;
     {
-        const int cmin = cbase - shift;                    // left-most column of this wave
+        const int cmin = cbase - shift;                    // left-most column of this tile
         if (cmin >= 1) jfirst = (cmin - 1) / kRows;
         if (jfirst > jlast + 1) jfirst = jlast + 1;
     }
@@ -480,91 +568,77 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     jfirst = 0;
 #endif
 
+    auto staged_now = [&]() -> int {
+        const int a = flags[16], b = flags[17];
+        return __builtin_amdgcn_readfirstlane(a < b ? a : b);
+    };
+    int staged_seen = 0;
+    int peek = 0, peek_sa = 0, peek_sb = 0;   // counter values on their way from LDS
+#ifdef CTCFA_STAMP   // tuning builds: where a tile's cycles go (tools/stamps2.py reads them from the lastcol workspace)
+    unsigned long long st_nbr = 0, st_staged = 0, st_t0 = __builtin_amdgcn_s_memtime();
+    int st_nbr_n = 0, st_staged_n = 0;
+#define CTCFA_STAMP_BEGIN() const unsigned long long st_a = __builtin_amdgcn_s_memtime()
+#define CTCFA_STAMP_END(acc, cnt) do { acc += __builtin_amdgcn_s_memtime() - st_a; ++cnt; } while (0)
+#else
+#define CTCFA_STAMP_BEGIN() do { } while (0)
+#define CTCFA_STAMP_END(acc, cnt) do { } while (0)
+#endif
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
-    for (int s = 0; s < nsteps; ++s) {
-        const int j = s - w;
-        if (j >= 0 && j < jfirst) {
-            if (__builtin_amdgcn_readfirstlane(*posflag) == 0) {   // still provably -1e9 everywhere in this block
-                if (w == wstar) {
-                    const int t = j * kRows + lane;
-                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
-                }
-                if constexpr (CK) {  // the table row this block would have ended in
-                    uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) bp[k] = __float_as_uint(kProbMax);
-                }
-                lds_barrier();
-                continue;
-            }
-            jfirst = 0;            // emissions are not log-probabilities: compute everything from here on
-        }
-        if (j >= 0 && j <= jlast) {
-            const int slot = j % NS;
-            const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
-            cur_slot = slot;
-#pragma unroll
-            for (int k = 0; k < K; ++k) gaddr[k] += delta;
-            const int q = j & 3;
-            // Cross-wave boundary column, four rows per LDS instruction (an LDS instruction costs
-            // the issuing wave ~3x a VALU one).  Ring w, index t % 128 = last column of wave w-1
-            // at row t.  Consumer: row i of this block needs row t-1 = 32j+i -> one broadcast
-            // ds_read_b128 per 4 rows.  Producer: row i belongs at index 32j+1+i, so the 16-byte
-            // groups are shifted by one row: component (i+1)%4, written after rows 2, 6, .., 30;
-            // row 31 stays in pub4.x and opens the next block's first group.
-            const uint32_t in_addr = bnd_base + static_cast<uint32_t>((w * kBndPitch + q * kRows) * 4);
-            uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 16);
-            if (w == wstar) {  // owner of the last label column: waves beyond it hold padding only,
-                               // so nothing that matters reads this wave's ring
-                if (lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
-            } else if (lane == 63 && w < wstar) {
-                out_addr = bnd_base + static_cast<uint32_t>(((w + 1) * kBndPitch + q * kRows) * 4);
-            }
 
-            // software pipeline: operands of row i+PF are requested while row i is computed
-            constexpr int PF = CTCFA_PF;
-            float2 emq[PF][K];
+    // one 32-row block; OWNER: this tile holds the last label column and also publishes its scores
+    auto block = [&](int j, auto owner_tag) {
+        constexpr bool OWNER = decltype(owner_tag)::value;
+        const int slot = j % NS;
+        const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
+        cur_slot = slot;
 #pragma unroll
-            for (int d = 0; d < PF; ++d) {
+        for (int k = 0; k < K; ++k) gaddr[k] += delta;
+        uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 16);
+        if (OWNER && lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
+
+        // software pipeline: operands of row i+PF are requested while row i is computed
+        constexpr int PF = CTCFA_PF;
+        float2 emq[PF][K];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * (PITCH * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            if (i % kHaloRows == 0) {   // group start: the neighbour's columns replace what went wrong in my halo
+#pragma unroll
+                for (int k = 0; k < K; ++k) prev[k] = is_halo ? hx[k] : prev[k];
+            }
+            float2 em[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
+            if (i + PF < kRows) {
 #pragma unroll
                 for (int k = 0; k < K; ++k)
-                    emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * (PITCH * 8));
+                    emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * (PITCH * 8));
             }
-            float4 lin4 = *reinterpret_cast<const float4*>(smem + in_addr);
-            float4 lin4_next = lin4;
-
+            // lane 0 has no left neighbour: it is a halo lane (its first column goes wrong at once, by
+            // design) or left padding (e = -inf: the sum loses whatever comes in)
+            const float leftv = dpp_wave_shr1_zero(prev[K - 1]);
 #pragma unroll
-            for (int i = 0; i < kRows; ++i) {
-                float2 em[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
-                if (i + PF < kRows) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k)
-                        emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * (PITCH * 8));
+            for (int k = K - 1; k >= 0; --k) {
+                const float pl = (k == 0) ? leftv : prev[k > 0 ? k - 1 : 0];
+                const float pk = prev[k];
+                const float a = pl + em[k].x;
+                const float b = pk + em[k].y;
+                const float nw = max3f(a, b, kProbMax);
+                if constexpr (!CK) {
+                    const float rsw = em[k].x - (nw - pl);
+                    const float rst = em[k].y - (nw - pk);
+                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
+                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
+                    dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
                 }
-                if (i % 4 == 0) {
-                    if (i > 0) lin4 = lin4_next;
-                    if (i + 4 < kRows) lin4_next = *reinterpret_cast<const float4*>(smem + in_addr + (i + 4) * 4);
-                }
-                const float lin = (i % 4 == 0) ? lin4.x : (i % 4 == 1) ? lin4.y : (i % 4 == 2) ? lin4.z : lin4.w;
-                const float leftv = dpp_wave_shr1(lin, prev[K - 1]);
-#pragma unroll
-                for (int k = K - 1; k >= 0; --k) {
-                    const float pl = (k == 0) ? leftv : prev[k > 0 ? k - 1 : 0];
-                    const float pk = prev[k];
-                    const float a = pl + em[k].x;
-                    const float b = pk + em[k].y;
-                    const float nw = max3f(a, b, kProbMax);
-                    if constexpr (!CK) {
-                        const float rsw = em[k].x - (nw - pl);
-                        const float rst = em[k].y - (nw - pk);
-                        // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
-                        const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
-                        dec[k] = __builtin_amdgcn_alignbit(dec[k], __float_as_uint(d), 31);
-                    }
-                    prev[k] = nw;
-                }
+                prev[k] = nw;
+            }
+            if constexpr (OWNER) {
                 if ((i + 1) % 4 == 0) pub4.x = prev[K - 1];
                 else if ((i + 1) % 4 == 1) pub4.y = prev[K - 1];
                 else if ((i + 1) % 4 == 2) pub4.z = prev[K - 1];
@@ -572,36 +646,134 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     pub4.w = prev[K - 1];
                     *reinterpret_cast<float4*>(smem + out_addr + (i - 2) * 4) = pub4;
                 }
-                // Pin this row's decisions here (empty asm = opaque use, no instruction): dec[] is
-                // consumed at the end of the block, and LLVM otherwise sinks the residual math of
-                // all 32 rows down to that store, keeping every operand alive (hundreds of spills).
+            }
+            // Pin this row's decisions here (empty asm = opaque use, no instruction): dec[] is
+            // consumed at the end of the block, and LLVM otherwise sinks the residual math of
+            // all 32 rows down to that store, keeping every operand alive (hundreds of spills).
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    if constexpr (CK) asm volatile("" : "+v"(prev[k]));  // (keeps the rows apart for the scheduler)
-                    else asm volatile("" : "+v"(dec[k]));
+            for (int k = 0; k < K; ++k) {
+                if constexpr (CK) asm volatile("" : "+v"(prev[k]));  // (keeps the rows apart for the scheduler)
+                else asm volatile("" : "+v"(dec[k]));
+            }
+            const int g = j * kGroups + i / kHaloRows;   // the group this row belongs to
+            if (i % kHaloRows == kHaloRows - 1 - kPollLead - kPeekLead) {
+                // the counters are read a few rows before they are looked at: no LDS round trip in the way
+                if (w > 0) peek = flags[w - 1];
+                if (i / kHaloRows == kGroups - 1) {   // (for the next block: no wait at its start)
+                    peek_sa = flags[16];
+                    peek_sb = flags[17];
                 }
             }
-            // decision words of this block (fire and forget: this wave never waits on vmcnt)
+            if (i % kHaloRows == kHaloRows - 1 - kPollLead) {
+                if (w > 0) {   // my neighbour's columns at the end of this group, for my next one
+#if CTCFA_TILE_PRIO == 6
+                    if (__builtin_amdgcn_readfirstlane(peek) < g + 1) __builtin_amdgcn_s_setprio(0);
+                    else {
+                        const int pr = W > 1 ? (w * 4) / W : 0;
+                        if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+                        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                        else __builtin_amdgcn_s_setprio(1);
+                    }
+#endif
+#if CTCFA_TILE_PRIO == 3
+                    // Issue slots of a SIMD go by priority, then age: a tile that keeps losing falls behind and
+                    // everybody upstream ends up waiting for it (ring space).  A tile that had to wait for its
+                    // neighbour is ahead and steps back; one that found the neighbour done is the one being
+                    // waited for and goes first.
+                    if (__builtin_amdgcn_readfirstlane(peek) < g + 1) __builtin_amdgcn_s_setprio(0);
+                    else __builtin_amdgcn_s_setprio(2);
+#endif
+                    if (__builtin_expect(__builtin_amdgcn_readfirstlane(peek) < g + 1, 0)) {   // (normally it is 4+ rows ahead)
+                        CTCFA_STAMP_BEGIN();
+                        int f, spins = 0;
+                        do {
+                            __builtin_amdgcn_s_sleep(1);
+                            f = __builtin_amdgcn_readfirstlane(flags[w - 1]);
+                            if (++spins > kSpinCap) { CTCFA_SPIN_DIAG("tile-nbr", w, g, f); break; }
+                        } while (f < g + 1);
+                        CTCFA_STAMP_END(st_nbr, st_nbr_n);
+                    }
+                    asm volatile("" ::: "memory");
+                    const float* xr = reinterpret_cast<const float*>(smem + xin_addr + static_cast<uint32_t>((g % XR) * XW * 4));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) hx[k] = xr[k];
+                }
+            }
+            if (i % kHaloRows == kHaloRows - 1) {   // group end: my last columns for the tile to my right, then the counter
+                if (publishes) {
+                    float* xw = reinterpret_cast<float*>(smem + xout_addr + static_cast<uint32_t>((g % XR) * XW * 4));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) xw[k] = prev[k];
+                    asm volatile("" ::: "memory");
+                    if (lane == 63) flags[w] = g + 1;
+                }
+            }
+        }
+        // trace words of this block (fire and forget: this wave never waits on vmcnt); halo lanes hold
+        // copies that have gone wrong by now
+        if (lane >= HL) {
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) bp[k] = CK ? __float_as_uint(prev[k]) : dec[k];
-            if (w == wstar) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
-                const int t = j * kRows + lane;
-                if (lane < kRows && t >= 1 && t < T)
-                    seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
-            }
-            // A tile that stops here (dead zone) will not open another group: hand its last row over
-            // now -- the next tile's first column is alive one row longer than this tile's last one.
-            if (j == jlast && jlast < nblk - 1 && lane == 63 && w < wstar)
-                bnd[(w + 1) * kBndPitch + ((j + 1) * kRows) % kBnd] = pub4.x;
         }
-        lds_barrier();
+        if constexpr (OWNER) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
+            const int t = j * kRows + lane;
+            if (lane < kRows && t >= 1 && t < T)
+                seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
+        }
+    };
+
+    for (int j = 0; j <= jlast; ++j) {
+        staged_seen = __builtin_amdgcn_readfirstlane(peek_sa < peek_sb ? peek_sa : peek_sb);
+#if CTCFA_TILE_PRIO == 3
+        if (w == 0) {   // (tile 0 has no neighbour to its left: it steps back when it runs into the producer)
+            if (staged_seen <= j) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+#endif
+        if (__builtin_expect(staged_seen <= j, 0)) {   // emissions of block j (normally seen staged while block j-1 was computed)
+            CTCFA_STAMP_BEGIN();
+            for (int spins = 0;; ++spins) {
+                staged_seen = staged_now();
+                if (staged_seen > j) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > kSpinCap) { CTCFA_SPIN_DIAG("tile-staged", w, j, staged_seen); break; }
+            }
+            CTCFA_STAMP_END(st_staged, st_staged_n);
+        }
+        asm volatile("" ::: "memory");
+        if (j < jfirst) {
+            if (__builtin_amdgcn_readfirstlane(*posflag) == 0) {   // still provably -1e9 everywhere in this block
+                if (w == wstar) {
+                    const int t = j * kRows + lane;
+                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
+                }
+                if constexpr (CK) {  // the table row this block would have ended in
+                    if (lane >= HL) {
+                        uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) bp[k] = __float_as_uint(kProbMax);
+                    }
+                }
+                if (lane == 63) flags[w] = kGroups * (j + 1);   // (its exchange rows are still the initial -1e9)
+                continue;
+            }
+            jfirst = 0;            // emissions are not log-probabilities: compute everything from here on
+        }
+        if (w == wstar) block(j, std::true_type{});
+        else block(j, std::false_type{});
     }
+    if (lane == 63) flags[w] = kBigCount;   // done (end of the segment or dead zone): nobody waits for this tile again
+#ifdef CTCFA_STAMP
+    if (lane == 0 && blockIdx.x < 64) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(lastcol) + (blockIdx.x * 16 + w) * 8;
+        o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = st_nbr; o[2] = st_staged; o[3] = st_nbr_n; o[4] = st_staged_n;
+        o[5] = jfirst; o[6] = jlast; o[7] = st_t0;
+    }
+    return;
+#endif
     // row 32*nblk (present when (T-1) % 32 == 0) is still in pub4.x
     if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;
-    };  // compute
-    if (KH == KL || my.role == kRoleHeavy) compute(std::integral_constant<int, KH>{});
-    else compute(std::integral_constant<int, KL>{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -877,6 +1049,7 @@ struct BtArgs {
     const int32_t* utt_begin;
     const uint32_t* bits;
     const float* lastcol;
+    const int32_t* fill_err;   // FillRoles::spin_timeout of the fill that produced bits / lastcol (NULL: none)
     BtParams p;
     int32_t* frame_of_label;
     float* char_prob;
@@ -945,6 +1118,10 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     if (sd.prestatus == kPreWindowed) return;  // windowed_kernel owns this segment
     if (sd.prestatus != 0) {
         fail(sd.prestatus);
+        return;
+    }
+    if (a.fill_err && *a.fill_err) {   // the fill gave up on a progress counter: its trace is not to be trusted
+        fail(5);
         return;
     }
 

@@ -183,6 +183,8 @@ def _raise_for_status(status):
         raise IndexError("CTC segmentation backtrack left the trellis")
     if status == _native.ST_WINDOWED_UNSUPPORTED:
         raise NotImplementedError("windowed DP regime with more than ~40 000 frames (one column must fit the LDS)")
+    if status == _native.ST_TEXT_TOO_LONG:
+        raise NotImplementedError("more label columns than one workgroup of the fill kernel covers (~5 400)")
     if status != _native.ST_OK:
         raise RuntimeError(f"ctcfa status {status}")
 

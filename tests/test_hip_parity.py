@@ -687,6 +687,9 @@ def test_fuzz_medium_shapes_tiles_and_zones(pkg, oracle, engine, seed):
         kw["backtrack_from_max_t"] = True
     if seed % 4 == 2:
         kw["preamble_transition_cost_zero"] = False
+    if K:   # a forced tile width covers 15 tiles of (64 - halo lanes) * K columns at most
+        cap = 15 * (64 - -(-16 // K)) * K - (K - 1)
+        segs = [s for s in segs if len(s[1]) <= cap]
     res, info = _run_plan(pkg, engine, segs, K, **kw)
     if K:
         assert info["cols_per_lane"] == K

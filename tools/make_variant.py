@@ -77,6 +77,18 @@ def patch_F(k, h):
     return k, h
 
 
+def patch_nobar(k, h):
+    """timing only (results race): no workgroup barrier in the steady state of the fill kernel (compute
+    tiles, V == pitch producer) -- upper bound of what neighbour-to-neighbour flags could gain"""
+    k = sub(k, "        lds_barrier();\n    }\n    // row 32*nblk", "    }\n    // row 32*nblk")
+    k = sub(k, "                lds_barrier();\n                continue;\n            }\n            jfirst = 0;", "                continue;\n            }\n            jfirst = 0;")
+    k = sub(k, "                if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }  // slot (s+1) % NS was last read in step s-1\n                lds_barrier();",
+            "                if (s + 1 < nblk) { vwrite(s + 1, ea); publish_flag(); }\n                __builtin_amdgcn_s_sleep(40);")
+    k = sub(k, "                if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }\n                lds_barrier();\n            }\n        } else if constexpr (VP > 32 && VP <= 64) {",
+            "                if (s + 2 < nblk) { vwrite(s + 2, eb); publish_flag(); }\n                __builtin_amdgcn_s_sleep(40);\n            }\n        } else if constexpr (VP > 32 && VP <= 64) {")
+    return k, h
+
+
 def patch_P(k, h):
     """backtrack kernel at wave priority 3 (above the fill kernel's 1/2)"""
     k = sub(k, "    if (sd.prestatus == kPreWindowed) return;  // windowed_kernel owns this segment", "    __builtin_amdgcn_s_setprio(3);\n    if (sd.prestatus == kPreWindowed) return;")
@@ -160,7 +172,7 @@ def patch_btstamp(k, h):
     return k, h
 
 
-PATCHES = {"nowait": patch_nowait, "btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
+PATCHES = {"nobar": patch_nobar, "nowait": patch_nowait, "btwalk": patch_btwalk, "Q4": patch_Q4, "Q1": patch_Q1, "Q2": patch_Q2, "Q3": patch_Q3, "P": patch_P, "F": patch_F, "G": patch_G, "btstamp": patch_btstamp, "A": patch_A, "C": patch_C, "D": patch_D, "stamp": patch_stamp, "base": lambda k, h: (k, h)}
 
 
 def main():

@@ -1,0 +1,40 @@
+"""Diagnostic only: per-tile cycle totals an instrumented build (-DCTCFA_STAMP) leaves in the lastcol
+workspace: total, waiting for the left neighbour, waiting for staged emissions.  The host passes
+char_prob as lastcol (variant patch) -- see tools/make_variant.py stamp2."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+pkg = ge.build()
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+syn = pkg.synthetic
+B, T, V, U, n = 512, 3000, 32, 22, 28
+lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n)
+C = gt.shape[1]
+cfg = pkg.CtcSegmentationParameters(index_duration=0.02)
+eng = pkg._native.Engine(0)
+plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=K)
+W = plan.info["waves_per_seg"]
+dev = torch.device("cuda:0")
+d_lpz = torch.from_numpy(lpz.reshape(-1)).to(dev)
+d_lab = torch.from_numpy(gt.astype(np.int32).reshape(-1)).to(dev)
+d_ub = torch.from_numpy(ub.astype(np.int32).reshape(-1)).to(dev)
+d_fol = torch.zeros(B * C, dtype=torch.int32, device=dev)
+d_cp = torch.zeros(B * T, dtype=torch.float32, device=dev)
+d_seg = torch.zeros(3, B * U, dtype=torch.float64, device=dev)
+d_te = torch.zeros(B, dtype=torch.int32, device=dev)
+d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+for _ in range(300):
+    plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), d_fol.data_ptr(), d_cp.data_ptr(), None,
+                    d_seg[0].data_ptr(), d_seg[1].data_ptr(), d_seg[2].data_ptr(), d_te.data_ptr(),
+                    d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+raw = d_cp.cpu().numpy().view(np.uint64)[: 64 * 16 * 8].reshape(64, 16, 8).astype(np.int64)
+for w in range(W):
+    r = raw[:, w, :]
+    print(f"tile {w}: total {np.median(r[:,0]):.0f} cyc  nbr-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  "
+          f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  blocks {np.median(r[:,5]):.0f}..{np.median(r[:,6]):.0f}  "
+          f"start +{np.median(r[:,7]-raw[:,0,7]):.0f}")
+r = raw[:, 15, :]
+print(f"producer: total {np.median(r[:,0]):.0f} cyc  space-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  load-wait + write {np.median(r[:,2]):.0f}  blocks {np.median(r[:,4]):.0f}")
