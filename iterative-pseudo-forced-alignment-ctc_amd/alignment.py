@@ -17,6 +17,7 @@ arguments and ``aligner.config.*`` fields as in src/test/test_ctc_segmentation.p
 lives on a GPU); ``get_segments`` runs the HIP DP engine.  ``get_segments_batch`` is the
 addition that lets the anchor-iteration / word-level callers put many windows in one launch.
 """
+import copy
 from pathlib import Path
 from types import SimpleNamespace
 
@@ -224,10 +225,12 @@ class CTCSegmentation:
         return utt_ids, text
 
     def prepare_segmentation_task(self, text, lpz, name=None, speech_len=None):
-        config = self.config
         if self.time_stamps == "auto" and speech_len is None:
             raise ValueError("speech_len is needed for time_stamps='auto'")
-        config.set(**self.get_timing_config(speech_len, lpz.shape[0]))
+        self.config.set(**self.get_timing_config(speech_len, lpz.shape[0]))
+        # every task keeps its OWN copy: with time_stamps="auto" the index duration differs from task
+        # to task, and a batch of tasks prepared up front must not all see the last one's value
+        config = copy.copy(self.config)
         utt_ids, text = self._split_text(text)
         if self.text_converter == "tokenize":
             tok = self._tokenizer
@@ -271,9 +274,17 @@ class CTCSegmentation:
         (``AssertionError`` for text longer than audio) instead of a dict."""
         if not tasks:
             return []
-        config = tasks[0].config
-        res = cs.get_segments_device(config, [t.lpz for t in tasks], [t.ground_truth_mat for t in tasks],
-                                     [t.utt_begin_indices for t in tasks], engine=self._engine_or_default())
+        # one launch per distinct parameter set (time_stamps="auto": the index duration is per task)
+        groups = {}
+        for i, t in enumerate(tasks):
+            groups.setdefault(repr(t.config), []).append(i)
+        res = [None] * len(tasks)
+        for idx in groups.values():
+            part = cs.get_segments_device(tasks[idx[0]].config, [tasks[i].lpz for i in idx],
+                                          [tasks[i].ground_truth_mat for i in idx],
+                                          [tasks[i].utt_begin_indices for i in idx], engine=self._engine_or_default())
+            for i, r in zip(idx, part):
+                res[i] = r
         out = []
         for task, r in zip(tasks, res):
             try:

@@ -90,6 +90,20 @@ int set_err(ctcfa_engine* e, int code, const std::string& msg) {
     return code;
 }
 
+// The engine's device for the duration of a call; the caller's (torch's) current device comes back after it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 #define HIP_TRY(eng, expr)                                                                   \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
@@ -200,61 +214,75 @@ int lds_bytes_fill(int NS, int W, int K, int VP) {
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
-// Launch-shape choice from a two-bound cost model of the fill kernel:
-//   a row of a K-column tile costs its wave  K gathers (LDS, ~12 cycles each for the issuing wave)
-//   + v K + 2 vector instructions (~4.4 cycles each), v = 3 in checkpoint mode, 9 with the decision math;
-//   a SIMD retires the same instructions at ~2.5 / ~3 cycles each           -> SIMD bound x tiles on the
-//                                                                               most loaded SIMD of a CU
-//   G workgroups share a CU (LDS, wave slots, VGPRs); a batch takes ceil(B / (G x CUs)) rounds.
+// Launch-shape choice from a two-bound cost model of the fill kernel (constants fitted
+// to tools/shape_search2.py sweeps, cycles per trellis row):
+//   one tile (wave) alone needs                62 + 21.4 K   (its own serial instruction issue)
+//   a SIMD retires a row of a K-column tile in  5 + 15 K     x tiles resident on the SIMD
+//   (decision-word mode: 6 more vector instructions per cell on both bounds);
+//   G workgroups share a CU (LDS, wave slots, VGPRs); a batch takes ceil(B / (G x CUs)) rounds;
+//   wide tiles lose a little more to contention than the bounds say (factor 1 + 0.03 K), and shapes
+//   that leave no room for two backtrack workgroups of the previous batch beside them pay 10 %.
 struct ShapeChoice { int K, W, NS; };
 
-int vgprs_of(int K) {  // compiled register counts (decision-word mode, the larger), rounded up to the allocation granule 8
+int vgprs_of(int K, bool ckpt) {  // compiled register counts, rounded up to the allocation granule 8
     switch (K) {
         case 1: case 2: return 64;
-        case 3: case 4: return 96;
-        case 5: return 112;
-        case 6: return 128;
-        case 8: return 160;
-        case 10: return 192;
-        case 12: return 224;
+        case 3: return ckpt ? 64 : 80;
+        case 4: return ckpt ? 88 : 96;
+        case 5: return ckpt ? 104 : 112;
+        case 6: return ckpt ? 112 : 128;
+        case 8: return ckpt ? 144 : 160;
+        case 10: return ckpt ? 168 : 192;
+        case 12: return ckpt ? 200 : 224;
         default: return 256;
     }
 }
+constexpr int kBacktrackVgprs = 104;   // backtrack_kernel<*>: 92..97 registers
 
 bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_cu, int force_k, int nprod,
                 bool ckpt, ShapeChoice* out) {
     double best_cost = -1.0;
     ShapeChoice best{0, 0, 0};
     const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
-    int NS = 4;
-    if (const char* e = std::getenv("CTCFA_NS")) NS = std::max(2, std::min(8, std::atoi(e)));
-    const double v = ckpt ? 3.0 : 9.0;
+    int ns_forced = 0;
+    if (const char* e = std::getenv("CTCFA_NS")) ns_forced = std::max(2, std::min(8, std::atoi(e)));
+    const double x = ckpt ? 0.0 : 6.0;   // extra vector instructions per cell for the decision math
+    auto r512 = [](int v) { return (v + 511) / 512 * 512; };  // LDS is handed out in 512-byte units
     for (int K : kKs) {
         if (force_k && K != force_k) continue;
         const int U = tile_useful_cols(K);
         const int W = (Cmax + (K - 1) + U - 1) / U;   // (the left padding can take up to K-1 columns)
         const int waves_per_wg = waves_of(W, nprod);
         if (W > 16 - nprod || (K >= 10 && waves_per_wg > 5) || (K == 8 && waves_per_wg > 8)) continue;  // launch bounds: K >= 10: 320 threads, K == 8: 512
+        // Ring slots: 4 (the producer up to three blocks ahead of the tiles); 3 when that is what lets the
+        // workgroups a CU needs, and two backtrack workgroups of the previous batch, share its LDS.
+        int NS = ns_forced ? ns_forced : 4;
+        if (!ns_forced) {
+            const int want = std::min(wg_per_cu_needed, 2);
+            if (want * r512(lds_bytes_fill(4, W, K, VP)) + 2 * r512(lds_beside) > lds_limit &&
+                want * r512(lds_bytes_fill(3, W, K, VP)) + 2 * r512(lds_beside) <= lds_limit)
+                NS = 3;
+            if (lds_bytes_fill(NS, W, K, VP) > lds_limit) NS = 3;
+        }
         const int lds = lds_bytes_fill(NS, W, K, VP);
         if (lds > lds_limit) continue;
-        auto r512 = [](int x) { return (x + 511) / 512 * 512; };  // LDS is handed out in 512-byte units
+        const int active = W + nprod;   // (padding waves leave at once)
         const int g_lds = std::max(lds_limit / r512(lds), 1);
-        const int g_wave = 32 / waves_per_wg;
-        const int g_vgpr = std::max(1, 4 * (512 / vgprs_of(K)) / std::min(waves_per_wg, W + nprod));
+        const int g_wave = std::max(32 / active, 1);
+        const int g_vgpr = std::max(1, 4 * (512 / vgprs_of(K, ckpt)) / active);
         int G = std::max(1, std::min(g_lds, std::min(g_wave, g_vgpr)));
-        // Pipelined schedule: the backtrack workgroups of the previous batch (lds_beside bytes each)
-        // run beside this fill; leave them room when the whole batch is resident at once.
-        if (G >= wg_per_cu_needed && wg_per_cu_needed > 1 &&
-            wg_per_cu_needed * r512(lds) + std::min(wg_per_cu_needed, 2) * r512(lds_beside) > lds_limit)
-            G = wg_per_cu_needed - 1;
-        if (G < 1) G = 1;
         const int g_eff = std::min(G, wg_per_cu_needed);
         const int rounds = (wg_per_cu_needed + G - 1) / G;
-        const double wave_bound = 12.0 * K + 4.4 * (v * K + 2.0);
-        const double tiles = std::ceil(g_eff * W / 4.0);
-        const double simd_bound = tiles * (3.0 * K + 2.5 * (v * K + 2.0));
-        const double waste = (double)(W * 64 * K) / (double)Cmax;   // columns computed per label column
-        const double cost = rounds * std::max(wave_bound, simd_bound) * (1.0 + 1e-3 * waste) + 1e-3 * waves_per_wg;
+        const double wave_bound = 62.0 + (21.4 + 5.0 * x) * K;
+        const double simd_bound = (g_eff * W / 4.0) * (5.0 + (15.0 + 2.5 * x) * K);
+        double cost = rounds * std::max(wave_bound, simd_bound) * (1.0 + 0.03 * K);
+        // pipelined schedule: two backtrack workgroups of the previous batch (4 waves, kBacktrackVgprs
+        // registers, lds_beside bytes each) want to sit beside the fill on every CU
+        const int act_cu = g_eff * active;
+        if (act_cu + 8 > 32 || vgprs_of(K, ckpt) * ((act_cu + 3) / 4) + 2 * kBacktrackVgprs > 512 ||
+            g_eff * r512(lds) + 2 * r512(lds_beside) > lds_limit)
+            cost *= 1.25;
+        cost += 1e-3 * waves_per_wg;
         if (best_cost < 0.0 || cost < best_cost) {
             best_cost = cost;
             best = {K, W, NS};
@@ -305,7 +333,7 @@ int ctcfa_engine_create(ctcfa_engine** out, int device) {
     if (device < 0 || device >= n) return set_err(nullptr, CTCFA_ERR_INVALID, "device out of range");
     ctcfa_engine* eng = new ctcfa_engine();
     eng->device = device;
-    HIP_TRY(eng, hipSetDevice(device));
+    DeviceGuard on_device(device);
     hipDeviceProp_t prop;
     HIP_TRY(eng, hipGetDeviceProperties(&prop, device));
     eng->num_cu = prop.multiProcessorCount;
@@ -394,7 +422,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     if (gather && !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO))
         return set_err(eng, CTCFA_ERR_UNSUPPORTED,
                        "vocab > 128 needs preamble_transition_cost_zero (the package default)");
-    HIP_TRY(eng, hipSetDevice(eng->device));
+    DeviceGuard on_device(eng->device);
 
     ctcfa_plan* pl = new ctcfa_plan();
     pl->eng = eng;
@@ -415,7 +443,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         }
     }
     pl->gather = gather;
-    const int nprod = 1;
+    // Vocabularies staged row by row (33..128 entries other than the vectorised pitch 64) take two
+    // producer waves, each staging every other row: one alone cannot keep six tiles fed.
+    const int nprod = (!gather && pl->VP > 32 && !(pl->VP == 64 && vocab == 64)) ? 2 : 1;
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.
@@ -774,6 +804,7 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
     bool want_seg = false;
     int rc = check_args(pl, a, &want_seg);
     if (rc != CTCFA_OK) return rc;
+    DeviceGuard on_device(eng->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     // a pipelined run may still be reading workspace 0 on the side stream
     if (pl->bt_pending[0]) {
@@ -800,8 +831,8 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     int rc = check_args(pl, a, &want_seg);
     if (rc != CTCFA_OK) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
+    DeviceGuard on_device(eng->device);
     if (!pl->side) {  // first use: second workspace, side stream, hand-over events
-        HIP_TRY(eng, hipSetDevice(eng->device));
         HIP_TRY(eng, hipMalloc(&pl->d_bits[1], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
         HIP_TRY(eng, hipMalloc(&pl->d_lastcol[1], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
         for (int q = 0; q < 2; ++q) {
@@ -870,6 +901,7 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
     if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
+    DeviceGuard on_device(eng->device);
     ctcfa_plan* pl = nullptr;
     int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true);
     if (rc != CTCFA_OK) return rc;

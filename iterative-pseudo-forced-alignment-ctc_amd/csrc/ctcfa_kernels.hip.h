@@ -164,7 +164,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // dynamic LDS = NS slots * kRows * (VP+2) * 8  +  exchange rings  +  last-column ring + counters.
 // ---------------------------------------------------------------------------------------
 template <int K, int VP, bool CK = false>
-__global__ void __attribute__((amdgpu_waves_per_eu(K <= 2 ? 8 : 1)))   // K <= 2: 64 VGPRs, room for the backtrack beside it
+__global__ void __attribute__((amdgpu_waves_per_eu(((K <= 2 || (K == 3 && CK)) && VP <= 64) ? 8 : 1)))   // narrow tiles: 64 VGPRs, room for the backtrack beside it
 __launch_bounds__((K >= 10) ? 320 : (K >= 8) ? 512 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
@@ -350,18 +350,29 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     *reinterpret_cast<float2*>(smem + spc + ((lv == 0) ? p * (RPP * PITCH * 8) : 0)) = sp;
                 }
             };
-            float4 ea[NP], eb[NP];
-            vload(0, ea);
-            for (int jb = 0; jb < nblk; jb += 2) {
-                if (jb + 1 < nblk) vload(jb + 1, eb);
-                wait_space(jb);
-                vwrite(jb, ea);
-                publish(jb);
-                if (jb + 1 >= nblk) break;
-                if (jb + 2 < nblk) vload(jb + 2, ea);
-                wait_space(jb + 1);
-                vwrite(jb + 1, eb);
-                publish(jb + 1);
+            if constexpr (VP == 32) {   // two register sets: loads run a block ahead of the LDS writes
+                float4 ea[NP], eb[NP];
+                vload(0, ea);
+                for (int jb = 0; jb < nblk; jb += 2) {
+                    if (jb + 1 < nblk) vload(jb + 1, eb);
+                    wait_space(jb);
+                    vwrite(jb, ea);
+                    publish(jb);
+                    if (jb + 1 >= nblk) break;
+                    if (jb + 2 < nblk) vload(jb + 2, ea);
+                    wait_space(jb + 1);
+                    vwrite(jb + 1, eb);
+                    publish(jb + 1);
+                }
+            } else {   // 64 entries: one set (32 registers; a second one would not fit the 64-register budget)
+                float4 ea[NP];
+                vload(0, ea);
+                for (int jb = 0; jb < nblk; ++jb) {
+                    wait_space(jb);
+                    vwrite(jb, ea);
+                    publish(jb);
+                    if (jb + 1 < nblk) vload(jb + 1, ea);
+                }
             }
         } else if constexpr (VP > 32 && VP <= 64) {
             // ---- one row per pass (character vocabularies between 33 and 64 entries that are not
@@ -403,18 +414,35 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
                     }
                 };
-                // One register set: the loads of block jb+1 are issued right after block jb has been written.
-                float ea[NR];
-                rload(0, ea);
-                for (int jb = 0; jb < nblk; ++jb) {
-                    wait_space(jb);
-                    rwrite(jb, ea);
-                    publish(jb);
-                    if (jb + 1 < nblk) rload(jb + 1, ea);
+                if constexpr (PARTS == 2) {
+                    // two register sets of 16 rows: the loads of a block are issued a whole block before
+                    // they are written (HBM latency never sits inside the staging of a block)
+                    float ea[NR], eb[NR];
+                    rload(0, ea);
+                    for (int jb = 0; jb < nblk; jb += 2) {
+                        if (jb + 1 < nblk) rload(jb + 1, eb);
+                        wait_space(jb);
+                        rwrite(jb, ea);
+                        publish(jb);
+                        if (jb + 1 >= nblk) break;
+                        if (jb + 2 < nblk) rload(jb + 2, ea);
+                        wait_space(jb + 1);
+                        rwrite(jb + 1, eb);
+                        publish(jb + 1);
+                    }
+                } else {
+                    // One register set: the loads of block jb+1 are issued right after block jb has been written.
+                    float ea[NR];
+                    rload(0, ea);
+                    for (int jb = 0; jb < nblk; ++jb) {
+                        wait_space(jb);
+                        rwrite(jb, ea);
+                        publish(jb);
+                        if (jb + 1 < nblk) rload(jb + 1, ea);
+                    }
                 }
             };
-            if (roles->nprod == 2) run(std::integral_constant<int, 2>{});
-            else run(std::integral_constant<int, 1>{});
+            run(std::integral_constant<int, 2>{});   // (the plan always gives this path two producers)
         } else if constexpr (PASSES == CH) {
             // whole block in one chunk (VP == 32, V < 32).  One register set: the loads of block jb+1 are
             // issued right after block jb has been written (the ring keeps the tiles fed meanwhile; a
@@ -430,56 +458,63 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             }
         } else if constexpr (VP > 64) {
             // ---- character vocabularies between 65 and 128 entries (e.g. 76 for French): a row per
-            // pass, lane i holds entries i and 64 + i, loads run a whole block ahead of their use
-            // (one register set, as above); lane 0 also writes the start-column pseudo entry.
+            // pass, lane i holds entries i and 64 + i; lane 0 also writes the start-column pseudo entry.
+            // With two producers each stages every other row.  One register set per producer: the loads
+            // of block jb+1 are issued right after block jb has been written.
             const int sv0 = lane < V ? lane : V - 1;
             const int sv1 = lane + 64 < V ? lane + 64 : V - 1;
-            auto wload = [&](int jb, float (&e0)[kRows], float (&e1)[kRows]) {
-                const int t0 = jb * kRows + 1;
+            auto runw = [&](auto parts_tag) {
+                constexpr int PARTS = decltype(parts_tag)::value;
+                constexpr int NR = kRows / PARTS;
+                auto wload = [&](int jb, float (&e0)[NR], float (&e1)[NR]) {
+                    const int t0 = jb * kRows + 1 + part;
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) {
-                    int t = t0 + r;
-                    t = t < T ? t : T - 1;
-                    const unsigned char* rowp = lpz_bytes + static_cast<uint32_t>(t * V) * 4u;
-                    e0[r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv0) * 4u);
-                    e1[r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv1) * 4u);
-                }
-            };
-            auto wwrite = [&](int jb, const float (&e0)[kRows], const float (&e1)[kRows]) {
-                unsigned char* slot = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES);
-                // lanes past the vocabulary park their stores on the pad entry VP + 1
-                unsigned char* d0 = slot + static_cast<uint32_t>((lane < V ? lane : VP + 1) * 8);
-                unsigned char* d1 = slot + static_cast<uint32_t>((lane + 64 < V ? lane + 64 : VP + 1) * 8);
-                unsigned char* dp = slot + static_cast<uint32_t>((lane == 0 ? VP : VP + 1) * 8);
-                const int t0 = jb * kRows + 1;
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) {
-                    const float lb = (blank < 64)
-                                         ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e0[r]), blank & 63))
-                                         : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1[r]), blank & 63));
-                    const bool valid = (t0 + r) < T;  // uniform
-                    notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
-                    float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
-                    float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
-                    float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                    if (!valid) {
-                        v0 = make_float2(0.f, 0.f);
-                        v1 = v0;
-                        vp = make_float2(-__builtin_inff(), 0.0f);
+                    for (int r = 0; r < NR; ++r) {
+                        int t = t0 + r * PARTS;
+                        t = t < T ? t : T - 1;
+                        const unsigned char* rowp = lpz_bytes + static_cast<uint32_t>(t * V) * 4u;
+                        e0[r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv0) * 4u);
+                        e1[r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv1) * 4u);
                     }
-                    *reinterpret_cast<float2*>(d0 + r * (PITCH * 8)) = v0;
-                    *reinterpret_cast<float2*>(d1 + r * (PITCH * 8)) = v1;
-                    *reinterpret_cast<float2*>(dp + r * (PITCH * 8)) = vp;
+                };
+                auto wwrite = [&](int jb, const float (&e0)[NR], const float (&e1)[NR]) {
+                    unsigned char* slot = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) + static_cast<uint32_t>(part * (PITCH * 8));
+                    // lanes past the vocabulary park their stores on the pad entry VP + 1
+                    unsigned char* d0 = slot + static_cast<uint32_t>((lane < V ? lane : VP + 1) * 8);
+                    unsigned char* d1 = slot + static_cast<uint32_t>((lane + 64 < V ? lane + 64 : VP + 1) * 8);
+                    unsigned char* dp = slot + static_cast<uint32_t>((lane == 0 ? VP : VP + 1) * 8);
+                    const int t0 = jb * kRows + 1 + part;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const float lb = (blank < 64)
+                                             ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e0[r]), blank & 63))
+                                             : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1[r]), blank & 63));
+                        const bool valid = (t0 + r * PARTS) < T;  // uniform
+                        notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
+                        float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
+                        float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
+                        float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
+                        if (!valid) {
+                            v0 = make_float2(0.f, 0.f);
+                            v1 = v0;
+                            vp = make_float2(-__builtin_inff(), 0.0f);
+                        }
+                        *reinterpret_cast<float2*>(d0 + r * (PARTS * PITCH * 8)) = v0;
+                        *reinterpret_cast<float2*>(d1 + r * (PARTS * PITCH * 8)) = v1;
+                        *reinterpret_cast<float2*>(dp + r * (PARTS * PITCH * 8)) = vp;
+                    }
+                };
+                float ea[NR], eb[NR];
+                wload(0, ea, eb);
+                for (int jb = 0; jb < nblk; ++jb) {
+                    wait_space(jb);
+                    wwrite(jb, ea, eb);
+                    publish(jb);
+                    if (jb + 1 < nblk) wload(jb + 1, ea, eb);
                 }
             };
-            float ea[kRows], eb[kRows];
-            wload(0, ea, eb);
-            for (int jb = 0; jb < nblk; ++jb) {
-                wait_space(jb);
-                wwrite(jb, ea, eb);
-                publish(jb);
-                if (jb + 1 < nblk) wload(jb + 1, ea, eb);
-            }
+            if (roles->nprod == 2) runw(std::integral_constant<int, 2>{});
+            else runw(std::integral_constant<int, 1>{});
         }
         return;
     }

@@ -193,6 +193,33 @@ def _is_device_tensor(x):
     return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
 
+def _validate_segments(lpz_list, labels, utt_begin_list):
+    """What NumPy would have refused in the package, refused before anything reaches the kernels
+    (they index emissions with the raw label): label ids outside the vocabulary, emissions of
+    different vocabulary sizes in one batch, utterance starts outside the label sequence."""
+    if not lpz_list:
+        return
+    V = int(lpz_list[0].shape[1])
+    for b, (l, g) in enumerate(zip(lpz_list, labels)):
+        if l.ndim != 2 or int(l.shape[1]) != V:
+            raise ValueError(f"segment {b}: emissions must be [T, {V}] like the first segment's, got {tuple(l.shape)}")
+        if len(g) < 2 or g[0] != -1:
+            raise ValueError(f"segment {b}: ground truth must start with -1 and hold at least one more label")
+        body = g[1:]
+        if body.size and (int(body.min()) < 0 or int(body.max()) >= V):
+            raise IndexError(f"segment {b}: label id outside the vocabulary [0, {V})")
+    if utt_begin_list is not None:
+        for b, (u, g) in enumerate(zip(utt_begin_list, labels)):
+            u = np.asarray(u)
+            C = len(g)
+            if u.ndim != 1 or len(u) < 1:
+                raise ValueError(f"segment {b}: utt_begin_indices must hold U + 1 indices")
+            # determine_utterance_segments reads timings[i-1], timings[i], timings[i+1] for every start i
+            # and timings[e-1], timings[e] for the closing index e
+            if len(u) > 1 and (int(u[:-1].min()) < 1 or int(u[:-1].max()) > C - 2 or int(u[-1]) < 1 or int(u[-1]) > C - 1):
+                raise IndexError(f"segment {b}: utterance start outside the label sequence (C = {C})")
+
+
 def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, engine=None, want_state=True):
     """Batch of segments through the HIP engine -> list of per-segment dicts.
 
@@ -206,6 +233,7 @@ def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, eng
     """
     engine = engine or default_engine()
     labels = [_labels_from_mat(g) for g in ground_truth_list]
+    _validate_segments(lpz_list, labels, utt_begin_list)
     if lpz_list and all(_is_device_tensor(l) for l in lpz_list):
         return _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state)
     lpz_list = [np.ascontiguousarray(l.cpu().numpy() if hasattr(l, "cpu") else l, dtype=np.float32) for l in lpz_list]

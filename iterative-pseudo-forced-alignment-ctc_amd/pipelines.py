@@ -9,9 +9,12 @@ and ``src/search_on_speech.py`` (:15-152), so the bash drivers can call
   DP requests are batched into single launches of the HIP engine instead of one
   ``get_segments`` call each (word_level_alignment.py:35, search_on_speech.py:45,
   iterative_utterance_alignment.py:436);
-* several processes shard the work deterministically by rank (files[rank::world]) instead of
-  racing for empty "claim" files (iterative_utterance_alignment.py:440-447); the
-  skip-if-result-exists resume rule is kept.
+* several processes (one per GPU: RANK / WORLD_SIZE / LOCAL_RANK, as torch.distributed.run sets
+  them) shard the work deterministically -- files / rows sorted by estimated cost and packed
+  greedily onto the ranks (``sharding.assign_units``) -- instead of racing for empty "claim" files
+  (iterative_utterance_alignment.py:440-447); the skip-if-result-exists resume rule is kept, a result
+  file appears only when it is complete (temporary file + rename), and the row-level stages gather
+  fixed-width result records on rank 0 (``sharding.gather_records``), which writes the one TSV.
 
 Audio is read through an ``opener(path)`` -> object with ``num_frames``, ``sample_rate`` and
 ``load(frame_offset, num_frames)``; the default opener reads PCM WAV with the stdlib
@@ -74,34 +77,77 @@ def result_path(dst, audio_path):
 
 
 # -------------------------------------------------------------------- utterance-level stage
+def _file_costs(df, paths):
+    """Work estimate per audio file: frames x label columns summed over its rows."""
+    costs = []
+    for path in paths:
+        rows = df[df["Sample_Path"] == path]
+        dur = (rows["End"].astype(float) - rows["Start"].astype(float)).clip(lower=0.0)
+        chars = rows["Transcription"].astype(str).str.len()
+        costs.append(float((dur * 50.0 * chars).sum()) + 1.0)
+    return costs
+
+
+def _write_tsv_atomic(path, rows, columns):
+    tmp = path + ".tmp.%d" % os.getpid()
+    write_tsv(tmp, rows, columns)
+    os.replace(tmp, path)   # a result file exists only when it is complete
+
+
 def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params, opener=WavFile,
                           rank=0, world=1, files_per_round=8):
     """File loop of iterative_utterance_alignment.main (:436-475), ``files_per_round`` files in
-    lockstep.  Returns the list of result TSV paths written by this rank."""
+    lockstep.  Returns the list of result TSV paths written by this rank.
+
+    Files are packed onto the ranks by estimated cost (every rank computes the same assignment), so
+    no claim file is needed; a file whose (non-empty) result TSV exists is skipped, as in the
+    reference (:440-443) -- an empty one is what a killed run of the reference leaves behind
+    (align_utterances.sh:105-107 deletes those) and is redone.  One failing file costs that file:
+    the round it was in is repeated file by file and the error is reported at the end."""
+    from . import sharding
     samples_to_frames_ratio = aligner.estimate_samples_to_frames_ratio()
+    paths = list(dict.fromkeys(df["Sample_Path"].tolist()))
+    mine = sharding.assign_units(_file_costs(df, paths), world)[rank]
     todo = []
-    for audio_path in list(dict.fromkeys(df["Sample_Path"].tolist()))[rank::world]:
+    for audio_path in (paths[i] for i in mine):
         out = result_path(dst, audio_path)
-        if os.path.isfile(out):
+        if os.path.isfile(out) and os.path.getsize(out) > 0:
             print("File " + str(out) + " already exist, skipping the alignment generation.")
             continue
-        open(out, "a").close()   # same marker the reference leaves while a file is in progress
         todo.append((audio_path, out))
-    written = []
+
+    def coroutine_for(audio_path):
+        rows = df[df["Sample_Path"] == audio_path].reset_index(drop=True).to_dict(orient="records")
+        vad_rows = vad_df[vad_df["Sample_Path"] == audio_path].reset_index(drop=True).to_dict(orient="records")
+        log = anchor.make_logger(logs_path, audio_path.split("/")[-1].replace(".wav", "")) if logs_path else None
+        return anchor.file_alignment(asr_model, opener(audio_path), audio_path, rows, vad_rows,
+                                     samples_to_frames_ratio, params, log)
+
+    def finish(audio_path, out, result):
+        table = [dict(zip(UTT_COLUMNS, r)) for r in result]
+        time_reference.restore_short_scores(table, params.short_utterance_len)
+        _write_tsv_atomic(out, table, UTT_COLUMNS)
+        written.append(out)
+
+    written, failed = [], []
     for k in range(0, len(todo), files_per_round):
         group = todo[k:k + files_per_round]
-        coroutines = []
-        for audio_path, _ in group:
-            rows = df[df["Sample_Path"] == audio_path].reset_index(drop=True).to_dict(orient="records")
-            vad_rows = vad_df[vad_df["Sample_Path"] == audio_path].reset_index(drop=True).to_dict(orient="records")
-            log = anchor.make_logger(logs_path, audio_path.split("/")[-1].replace(".wav", "")) if logs_path else None
-            coroutines.append(anchor.file_alignment(asr_model, opener(audio_path), audio_path, rows, vad_rows,
-                                                    samples_to_frames_ratio, params, log))
-        for (audio_path, out), result in zip(group, anchor.run_batched(coroutines, aligner)):
-            table = [dict(zip(UTT_COLUMNS, r)) for r in result]
-            time_reference.restore_short_scores(table, params.short_utterance_len)
-            write_tsv(out, table, UTT_COLUMNS)
-            written.append(out)
+        try:
+            results = anchor.run_batched([coroutine_for(p) for p, _ in group], aligner)
+            for (audio_path, out), result in zip(group, results):
+                finish(audio_path, out, result)
+        except Exception as exc:   # which file it was is not known in a lockstep round: redo it file by file
+            print("Alignment round failed ({0}: {1}); repeating its files one at a time.".format(type(exc).__name__, exc))
+            for audio_path, out in group:
+                if out in written:
+                    continue
+                try:
+                    finish(audio_path, out, anchor.run_batched([coroutine_for(audio_path)], aligner)[0])
+                except Exception as one:
+                    print("File {0} could not be aligned ({1}: {2}).".format(audio_path, type(one).__name__, one))
+                    failed.append((audio_path, one))
+    if failed:
+        print("{0} file(s) failed on rank {1}: {2}".format(len(failed), rank, [p for p, _ in failed]))
     return written
 
 
@@ -143,13 +189,25 @@ def _aligned_lines(aligner, tasks):
     return out
 
 
-def align_words(asr_model, aligner, df, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
-                right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
-    """Row loop of word_level_alignment.main (:35-135) -> result rows (WORD_COLUMNS)."""
+def _word_row(row, clip_start, start, end, score):
+    """Result row of word_level_alignment.py:112-128 from the kept segment's (offset) times."""
+    audio_path = row["Sample_Path"]
+    audio_name = audio_path.split("/")[-1]
+    extension = audio_name.split(".")[-1]
+    abs_start, abs_end = clip_start + start, clip_start + end
+    sample_id = "_".join([audio_name.replace(extension, ""), str(abs_start), str(abs_end)])
+    return [sample_id, audio_path, end - start, abs_start, abs_end, score, row["Normalized_Transcription"],
+            row["Speaker_ID"], row["Wanted_Text"].lower(), row["Database"]]
+
+
+def word_hits(asr_model, aligner, records, indices, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
+              right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
+    """Row loop of word_level_alignment.main (:35-135) over ``records[i] for i in indices`` ->
+    fixed-width records ``(i, clip_start, start, end, score)``: what a rank hands to the gather."""
     log = log or (lambda m: None)
-    records = df.to_dict(orient="records")
     prepared = []
-    for row in records:
+    for i in indices:
+        row = records[i]
         audio_path = row["Sample_Path"]
         if time_info:
             clip_start, clip_end = float(row["Start"]), float(row["End"])
@@ -167,22 +225,19 @@ def align_words(asr_model, aligner, df, opener=WavFile, time_info=True, offset_t
             break   # the reference stops the whole run here (:63-66)
         text = sentence_pieces(text_prep.normalize_transcript(row["Normalized_Transcription"], number_to_words).upper(),
                                row["Wanted_Text"])
-        prepared.append((row, clip_start, clip_end, waveform, text))
+        prepared.append((i, row, clip_start, clip_end, waveform, text))
     out = []
     for k in range(0, len(prepared), rows_per_launch):
         chunk = prepared[k:k + rows_per_launch]
         tasks = []
-        for row, _, _, waveform, text in chunk:
+        for _, row, _, _, waveform, text in chunk:
             lpz = aligner.get_lpz(waveform)
             tasks.append(aligner.prepare_segmentation_task(text, lpz, row["Sample_ID"], waveform.shape[0]))
-        for (row, clip_start, clip_end, _, _), lines in zip(chunk, _aligned_lines(aligner, tasks)):
-            audio_path = row["Sample_Path"]
-            audio_name = audio_path.split("/")[-1]
-            extension = audio_name.split(".")[-1]
+        for (i, row, clip_start, clip_end, _, _), lines in zip(chunk, _aligned_lines(aligner, tasks)):
             wanted = row["Wanted_Text"]
             if isinstance(lines, AssertionError):
                 log(str(lines))
-                log("File {0} sequence from {1} to {2} is shorter than text: {3}".format(audio_path, clip_start, clip_end, wanted))
+                log("File {0} sequence from {1} to {2} is shorter than text: {3}".format(row["Sample_Path"], clip_start, clip_end, wanted))
                 continue
             for seg in lines:
                 if len(seg) != 6:
@@ -192,26 +247,47 @@ def align_words(asr_model, aligner, df, opener=WavFile, time_info=True, offset_t
                     start = float(seg[2]) + offset_time + left_offset
                     end = float(seg[3]) + offset_time + right_offset
                     score = float(seg[4])
-                    abs_start, abs_end = clip_start + start, clip_start + end
-                    sample_id = "_".join([audio_name.replace(extension, ""), str(abs_start), str(abs_end)])
-                    log("{0} | {1} | {2} | {3}".format(round(abs_start, 3), round(abs_end, 3), round(score, 3), seg[-1]))
-                    out.append([sample_id, audio_path, end - start, abs_start, abs_end, score,
-                                row["Normalized_Transcription"], row["Speaker_ID"], wanted.lower(), row["Database"]])
+                    log("{0} | {1} | {2} | {3}".format(round(clip_start + start, 3), round(clip_start + end, 3), round(score, 3), seg[-1]))
+                    out.append((float(i), clip_start, start, end, score))
     return out
 
 
+def align_words(asr_model, aligner, df, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
+                right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
+    """Row loop of word_level_alignment.main (:35-135) -> result rows (WORD_COLUMNS)."""
+    records = df.to_dict(orient="records")
+    hits = word_hits(asr_model, aligner, records, range(len(records)), opener, time_info, offset_time, left_offset,
+                     right_offset, log, rows_per_launch, number_to_words)
+    return [_word_row(records[int(i)], cs, st, en, sc) for i, cs, st, en, sc in hits]
+
+
 # --------------------------------------------------------------------- search-on-speech stage
-def search_on_speech(asr_model, aligner, df, wanted_text, opener=WavFile, offset_time=0.0, left_offset=0.0,
-                     right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
-    """Row loop of search_on_speech.main (:45-120) -> result rows (SOS_COLUMNS)."""
-    log = log or (lambda m: None)
+def _sos_row(row, wanted_text, clip_start, start, end, score):
+    """Result row of search_on_speech.py:97-113."""
+    audio_path = row["Sample_Path"]
+    audio_name = audio_path.split("/")[-1]
+    extension = audio_name.split(".")[-1]
+    abs_start, abs_end = clip_start + start, clip_start + end
+    sample_id = "_".join([audio_name.replace(extension, ""), str(abs_start), str(abs_end)])
+    return [sample_id, audio_path, end - start, abs_start, abs_end, score, row["Speaker_ID"], wanted_text.lower(),
+            row["Database"]]
+
+
+def normalized_query(wanted_text, number_to_words=None):
     if wanted_text == "":
         raise Exception("Sorry, empty text cannot be searched on speech.")
-    wanted_text = text_prep.normalize_transcript(wanted_text, number_to_words).upper()
+    return text_prep.normalize_transcript(wanted_text, number_to_words).upper()
+
+
+def search_hits(asr_model, aligner, records, indices, wanted_text, opener=WavFile, offset_time=0.0, left_offset=0.0,
+                right_offset=0.0, log=None, rows_per_launch=256):
+    """Row loop of search_on_speech.main (:45-120) over ``records[i] for i in indices`` (``wanted_text``
+    already normalised) -> records ``(i, clip_start, start, end, score)``."""
+    log = log or (lambda m: None)
     query = "·" + wanted_text.strip() + "·"
-    records = df.to_dict(orient="records")
     prepared, waveform = [], None
-    for row in records:
+    for i in indices:
+        row = records[i]
         clip_start, clip_end = float(row["Start"]), float(row["End"])
         try:
             src = opener(row["Sample_Path"])
@@ -219,21 +295,18 @@ def search_on_speech(asr_model, aligner, df, wanted_text, opener=WavFile, offset
             waveform = asr_model.audio_normalizer(clip, sr)
         except Exception:   # the reference prints and goes on with the previous row's audio (:66-67)
             print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
-        prepared.append((row, clip_start, clip_end, waveform))
+        prepared.append((i, row, clip_start, clip_end, waveform))
     out = []
     for k in range(0, len(prepared), rows_per_launch):
         chunk = prepared[k:k + rows_per_launch]
         tasks = []
-        for row, _, _, wf in chunk:
+        for _, row, _, _, wf in chunk:
             lpz = aligner.get_lpz(wf)
             tasks.append(aligner.prepare_segmentation_task(query, lpz, row["Sample_ID"], wf.shape[0]))
-        for (row, clip_start, clip_end, _), lines in zip(chunk, _aligned_lines(aligner, tasks)):
-            audio_path = row["Sample_Path"]
-            audio_name = audio_path.split("/")[-1]
-            extension = audio_name.split(".")[-1]
+        for (i, row, clip_start, clip_end, _), lines in zip(chunk, _aligned_lines(aligner, tasks)):
             if isinstance(lines, AssertionError):
                 log(str(lines))
-                log("File {0} sequence from {1} to {2} is shorter than text: {3}".format(audio_path, clip_start, clip_end, wanted_text))
+                log("File {0} sequence from {1} to {2} is shorter than text: {3}".format(row["Sample_Path"], clip_start, clip_end, wanted_text))
                 continue
             for seg in lines:
                 if len(seg) != 6:
@@ -243,23 +316,30 @@ def search_on_speech(asr_model, aligner, df, wanted_text, opener=WavFile, offset
                     start = float(seg[2]) + offset_time + left_offset
                     end = float(seg[3]) + offset_time + right_offset
                     score = float(seg[4])
-                    abs_start, abs_end = clip_start + start, clip_start + end
-                    sample_id = "_".join([audio_name.replace(extension, ""), str(abs_start), str(abs_end)])
-                    log("{0} | {1} | {2} | {3}".format(round(abs_start, 3), round(abs_end, 3), round(score, 3),
+                    log("{0} | {1} | {2} | {3}".format(round(clip_start + start, 3), round(clip_start + end, 3), round(score, 3),
                                                        seg[-1].replace("·", "")))
-                    out.append([sample_id, audio_path, end - start, abs_start, abs_end, score, row["Speaker_ID"],
-                                wanted_text.lower(), row["Database"]])
+                    out.append((float(i), clip_start, start, end, score))
     return out
 
 
-# --------------------------------------------------------------------------------- CLI mains
-def _load_model_and_aligner(args, **aligner_kwargs):
-    from speechbrain.pretrained import EncoderASR   # the acoustic model stays SpeechBrain's
+def search_on_speech(asr_model, aligner, df, wanted_text, opener=WavFile, offset_time=0.0, left_offset=0.0,
+                     right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
+    """Row loop of search_on_speech.main (:45-120) -> result rows (SOS_COLUMNS)."""
+    wanted_text = normalized_query(wanted_text, number_to_words)
+    records = df.to_dict(orient="records")
+    hits = search_hits(asr_model, aligner, records, range(len(records)), wanted_text, opener, offset_time, left_offset,
+                       right_offset, log, rows_per_launch)
+    return [_sos_row(records[int(i)], wanted_text, cs, st, en, sc) for i, cs, st, en, sc in hits]
 
-    from .alignment import CTCSegmentation
-    run_opts = {"device": "cuda"} if _gpu_available() else None
-    asr_model = EncoderASR.from_hparams(source=args.asr_hub, savedir=args.asr_savedir, run_opts=run_opts)
-    return asr_model, CTCSegmentation(asr_model, kaldi_style_text=False, time_stamps="fixed", **aligner_kwargs)
+
+# --------------------------------------------------------------------------------- CLI mains
+def _rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def _local_device():
+    """One process per GPU: LOCAL_RANK picks the device of this process (torch.distributed.run sets it)."""
+    return int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def _gpu_available():
@@ -270,8 +350,68 @@ def _gpu_available():
         return False
 
 
-def _rank_world():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+def _load_model_and_aligner(args, **aligner_kwargs):
+    from speechbrain.pretrained import EncoderASR   # the acoustic model stays SpeechBrain's
+
+    from . import _native
+    from .alignment import CTCSegmentation
+    run_opts, engine = None, None
+    if _gpu_available():
+        import torch
+        dev = _local_device()
+        torch.cuda.set_device(dev)
+        run_opts = {"device": "cuda:%d" % dev}
+        engine = _native.Engine(dev)   # the DP engine of THIS rank's GPU, not device 0
+    asr_model = EncoderASR.from_hparams(source=args.asr_hub, savedir=args.asr_savedir, run_opts=run_opts)
+    return asr_model, CTCSegmentation(asr_model, kaldi_style_text=False, time_stamps="fixed", engine=engine,
+                                      **aligner_kwargs)
+
+
+def _process_group():
+    """(dist or None, rank, world): joins the default process group when WORLD_SIZE > 1 -- "nccl"
+    (= RCCL over xGMI) when this process has a GPU, "gloo" otherwise (CPU tests)."""
+    rank, world = _rank_world()
+    if world <= 1:
+        return None, 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if _gpu_available() and os.environ.get("CTCFA_DIST_BACKEND", "nccl") == "nccl":
+            torch.cuda.set_device(_local_device())
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", _local_device()))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, dist.get_rank(), dist.get_world_size()
+
+
+def _row_costs(records):
+    """Work estimate per row: frames x label columns."""
+    costs = []
+    for r in records:
+        try:
+            dur = max(0.0, float(r["End"]) - float(r["Start"]))
+        except Exception:
+            dur = float(r.get("Audio_Length", 1.0) or 1.0)
+        text = str(r.get("Normalized_Transcription", r.get("Transcription", "")))
+        costs.append(dur * 50.0 * (len(text) + 2) + 1.0)
+    return costs
+
+
+def _gather_hits(dist, hits, world):
+    """Every rank's (row, clip_start, start, end, score) records -> all of them, in row order (the
+    single exchange of the row-level stages; role of src/postprocess/merge_aligned_files.py:17-25)."""
+    if dist is None:
+        return sorted(hits, key=lambda h: h[0])
+    import torch
+
+    from . import sharding
+    on_gpu = dist.get_backend() == "nccl"
+    local = torch.tensor(hits, dtype=torch.float64).reshape(-1, 5)
+    if on_gpu:
+        local = local.cuda()
+    return [tuple(r) for r in sharding.merge_in_unit_order(sharding.gather_records(local, dist), None)]
 
 
 def utterance_parser():
@@ -330,24 +470,42 @@ def word_parser(search=False):
 
 
 def word_main(args, asr_model=None, aligner=None, opener=WavFile, number_to_words=None):
+    """word_level_alignment.main for one process of WORLD_SIZE: this rank aligns its share of the
+    rows, the records are gathered, rank 0 writes ``<name>_words.tsv`` (the other ranks return None)."""
+    from . import sharding
     if asr_model is None:
         asr_model, aligner = _load_model_and_aligner(args)
-    log = anchor.make_logger(args.logs_path, args.tsv_path.split("/")[-1].replace(".tsv", "")) if args.logs_path else None
-    rows = align_words(asr_model, aligner, read_tsv(args.tsv_path), opener, args.time_info, args.offset_time,
-                       args.left_offset, args.right_offset, log, number_to_words=number_to_words)
+    dist, rank, world = _process_group()
+    log = anchor.make_logger(args.logs_path, args.tsv_path.split("/")[-1].replace(".tsv", "") + ("" if world == 1 else ".rank%d" % rank)) \
+        if args.logs_path else None
+    records = read_tsv(args.tsv_path).to_dict(orient="records")
+    mine = sharding.assign_units(_row_costs(records), world)[rank]
+    hits = word_hits(asr_model, aligner, records, mine, opener, args.time_info, args.offset_time, args.left_offset,
+                     args.right_offset, log, number_to_words=number_to_words)
+    hits = _gather_hits(dist, hits, world)
+    if rank != 0:
+        return None
     out = args.tsv_path.replace("_filtered.tsv", "_words.tsv")
-    write_tsv(out, rows, WORD_COLUMNS)
+    _write_tsv_atomic(out, [_word_row(records[int(i)], cs, st, en, sc) for i, cs, st, en, sc in hits], WORD_COLUMNS)
     return out
 
 
 def search_main(args, asr_model=None, aligner=None, opener=WavFile, number_to_words=None):
-    if args.text == "":
-        raise Exception("Sorry, empty text cannot be searched on speech.")
+    """search_on_speech.main, sharded and gathered like ``word_main``; rank 0 writes ``<name>_sos.tsv``."""
+    from . import sharding
+    wanted = normalized_query(args.text, number_to_words)
     if asr_model is None:
         asr_model, aligner = _load_model_and_aligner(args)
-    log = anchor.make_logger(args.logs_path, args.tsv_path.split("/")[-1].replace(".tsv", "")) if args.logs_path else None
-    rows = search_on_speech(asr_model, aligner, read_tsv(args.tsv_path), args.text, opener, args.offset_time,
-                            args.left_offset, args.right_offset, log, number_to_words=number_to_words)
+    dist, rank, world = _process_group()
+    log = anchor.make_logger(args.logs_path, args.tsv_path.split("/")[-1].replace(".tsv", "") + ("" if world == 1 else ".rank%d" % rank)) \
+        if args.logs_path else None
+    records = read_tsv(args.tsv_path).to_dict(orient="records")
+    mine = sharding.assign_units(_row_costs(records), world)[rank]
+    hits = search_hits(asr_model, aligner, records, mine, wanted, opener, args.offset_time, args.left_offset,
+                       args.right_offset, log)
+    hits = _gather_hits(dist, hits, world)
+    if rank != 0:
+        return None
     out = os.path.join(args.dst_path, args.tsv_path.split("/")[-1].replace(".tsv", "") + "_sos.tsv")
-    write_tsv(out, rows, SOS_COLUMNS)
+    _write_tsv_atomic(out, [_sos_row(records[int(i)], wanted, cs, st, en, sc) for i, cs, st, en, sc in hits], SOS_COLUMNS)
     return out

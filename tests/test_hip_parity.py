@@ -714,16 +714,17 @@ def test_fuzz_windowed_regime(pkg, oracle, V, blank, flags):
         _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
 
 
-def test_mixed_shape_with_four_column_heavy_tiles(pkg, oracle, engine):
-    """C in (1024, 1280] with enough workgroups to pair up: the launch model takes the mixed 8-wave
-    shape with KH = 4, KL = 2 (4 x 256 + 2 x 128 columns)."""
+def test_wide_segments_in_a_full_batch(pkg, oracle, engine):
+    """C in (1024, 1280] with two workgroups per CU: eight or more tiles per segment, every one of
+    them refreshing its halo from its neighbour twice per 32-row block."""
     syn = pkg.synthetic
     base = [syn.make_segment(6000 + s, T, 32, U, n) for s, (T, U, n) in
             enumerate([(2000, 44, 27), (1700, 40, 29), (1500, 41, 30)])]
     assert all(1024 < len(s[1]) <= 1280 for s in base)
     segs = [base[i % 3] for i in range(510)]
     res, info = _run_plan(pkg, engine, segs)
-    assert (info["cols_per_lane"], info["waves_per_seg"]) == (4, 6), info
+    K, W = info["cols_per_lane"], info["waves_per_seg"]
+    assert W * (64 - -(-16 // K)) * K >= max(len(s[1]) for s in base), info   # the tiles cover the widest segment
     _check(pkg, oracle, base, res[:3])
     for i in range(3, len(segs)):
         assert np.array_equal(res[i]["frame_of_label"], res[i % 3]["frame_of_label"])

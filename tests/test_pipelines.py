@@ -111,3 +111,39 @@ def test_wav_reader(pkg, tmp_path):
     clip, sr = f.load(4000, 8000)
     assert clip.shape == (8000, 1) and sr == 16000
     np.testing.assert_allclose(clip[:, 0].numpy(), data[4000:12000] / 32768.0, atol=1e-7)
+
+
+def test_utterance_stage_failure_costs_one_file_and_resume_redoes_empty_results(pkg, tmp_path, capsys):
+    """A file that cannot be aligned costs that file only (no empty result left behind, the others of
+    its lockstep round are written); a 0-byte result TSV -- what a killed run of the reference leaves
+    (align_utterances.sh:105-107) -- is not taken for a finished file."""
+    pl = _pipelines(pkg)
+    anchor = importlib.import_module(pkg.__name__ + ".anchor")
+    sc = [s for s in ANCHOR_GOLD["scenarios"] if s["name"] == "mixed_two_vad"][0]
+    base = [dict(r) for r in ANCHOR_GOLD["tsv_rows"][: sc["n_rows"]]]
+    files = ["data/a/good0.wav", "data/a/broken.wav", "data/a/good1.wav"]
+    df = pd.DataFrame([dict(r, Sample_Path=f) for f in files for r in base])
+    vad = pd.DataFrame([dict(Sample_Path=f, Start=s, End=e, Segment_Length=e - s) for f in files for s, e in sc["vad"]])
+    dst = tmp_path / "results"
+    dst.mkdir()
+    (dst / "good1.tsv").write_text("")   # stale empty result of an earlier, killed run
+    params = anchor.AnchorParams(**sc["params"])
+
+    class Broken(ZeroAudio):
+        num_frames = property(lambda self: (_ for _ in ()).throw(RuntimeError("unreadable audio")), lambda self, v: None)
+
+    def opener(path):
+        if "broken" in path:
+            return Broken(sc["audio_seconds"])
+        return ZeroAudio(sc["audio_seconds"])
+    written = pl.align_utterance_files(ScriptedASR(), ScriptedAligner(mode=sc["mode"], salt=sc["salt"]), df, vad,
+                                       str(dst), "", params, opener)
+    assert sorted(os.path.basename(p) for p in written) == ["good0.tsv", "good1.tsv"]
+    assert not (dst / "broken.tsv").exists()
+    assert (dst / "good1.tsv").stat().st_size > 0
+    assert not [f for f in os.listdir(dst) if ".tmp." in f]
+    assert "broken.wav" in capsys.readouterr().out
+    # resume: the two finished files are skipped, the broken one is tried again (and fails again)
+    again = pl.align_utterance_files(ScriptedASR(), ScriptedAligner(mode=sc["mode"], salt=sc["salt"]), df, vad,
+                                     str(dst), "", params, opener)
+    assert again == []

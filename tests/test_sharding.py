@@ -14,32 +14,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
 import importlib, json, os, sys
+from types import SimpleNamespace
 sys.path.insert(0, {root!r})
-import numpy as np, pandas as pd, torch
-import torch.distributed as dist
+import pandas as pd
 import __graft_entry__ as ge
 from tests.fakes import ScriptedAligner, ScriptedASR
 from tests.test_anchor import ZeroAudio
 pkg = ge.build()
 pl = importlib.import_module(pkg.__name__ + ".pipelines")
-sh = importlib.import_module(pkg.__name__ + ".sharding")
-dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-rank, world = dist.get_rank(), dist.get_world_size()
-case = json.load(open({gold!r}))["words"][0]
-df = pd.DataFrame(case["rows"])
-costs = [(float(r["End"]) - float(r["Start"])) for r in case["rows"]]
-units = sh.assign_units(costs, world)
-mine = df.iloc[units[rank]].reset_index(drop=True)
-rows = pl.align_words(ScriptedASR(), ScriptedAligner(mode=case["mode"], salt=case["salt"]), mine,
-                      opener=lambda p: ZeroAudio(case["audio_seconds"]), **case["args"])
-# fixed-width records: unit id, start, end, score  (text columns stay with the unit table)
-recs = [[float(units[rank][i]), r[3], r[4], r[5]] for i, r in enumerate(rows)] if len(rows) == len(mine) else None
-assert recs is not None, "every row of this fixture yields exactly one word segment"
-local = torch.tensor(recs, dtype=torch.float64).reshape(-1, 4)
-gathered = sh.gather_records(local, dist)
-merged = sh.merge_in_unit_order(gathered, units)
-if rank == 0:
-    json.dump(dict(merged=merged, units=units), open({out!r}, "w"))
+gold = json.load(open({gold!r}))
+# the PRODUCT mains, one process per rank (RANK / WORLD_SIZE / MASTER_* from the environment; gloo on CPU)
+case = gold["words"][{wcase}]
+args = SimpleNamespace(tsv_path={wtsv!r}, logs_path="", **case["args"])
+w = pl.word_main(args, ScriptedASR(), ScriptedAligner(mode=case["mode"], salt=case["salt"]),
+                 opener=lambda p: ZeroAudio(case["audio_seconds"]))
+case = gold["search"][{scase}]
+args = SimpleNamespace(tsv_path={stsv!r}, dst_path={dst!r}, logs_path="", text=case["text"], **case["args"])
+s = pl.search_main(args, ScriptedASR(), ScriptedAligner(mode=case["mode"], salt=case["salt"]),
+                   opener=lambda p: ZeroAudio(case["audio_seconds"]))
+rank = int(os.environ["RANK"])
+assert (w is None) == (rank != 0) and (s is None) == (rank != 0), "only rank 0 writes"
+import torch.distributed as dist
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -64,22 +59,50 @@ def test_assign_units_is_deterministic_and_balanced(pkg):
     assert sh.assign_units(costs, 1) == [list(range(8))]
 
 
-def test_two_rank_gloo_word_alignment_equals_single_process(pkg, tmp_path):
-    gold = os.path.join(ROOT, "tests", "golden", "words_traces.json")
-    out = str(tmp_path / "merged.json")
+def _same(a, b):
+    if isinstance(a, float) or isinstance(b, float):
+        return float(a) == float(b) or (np.isnan(float(a)) and np.isnan(float(b)))
+    return a == b
+
+
+@pytest.mark.parametrize("wcase,scase", [(0, 0), (1, 1), (3, 2)])
+def test_two_rank_gloo_product_mains_equal_the_reference(pkg, tmp_path, wcase, scase):
+    """pipelines.word_main / search_main on two gloo ranks: rows sharded by cost, records gathered,
+    rank 0 writes the TSVs -- byte-compatible with the reference's own single-process output."""
+    import pandas as pd
+    gold_path = os.path.join(ROOT, "tests", "golden", "words_traces.json")
+    gold = json.load(open(gold_path))
+    wtsv = str(tmp_path / "corpus_filtered.tsv")
+    stsv = str(tmp_path / "segments.tsv")
+    pd.DataFrame(gold["words"][wcase]["rows"]).to_csv(wtsv, sep="\t", index=None)
+    pd.DataFrame(gold["search"][scase]["rows"]).to_csv(stsv, sep="\t", index=None)
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, gold=gold, out=out))
+    script.write_text(WORKER.format(root=ROOT, gold=gold_path, wcase=wcase, scase=scase, wtsv=wtsv, stsv=stsv,
+                                    dst=str(tmp_path)))
     port = _free_port()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    res = json.load(open(out))
-    case = json.load(open(gold))["words"][0]
-    # single-process reference result (the reference's own output TSV rows, in row order)
-    assert len(res["merged"]) == len(case["out"])
-    for rec, ref in zip(res["merged"], case["out"]):
-        assert rec[1] == ref[3] and rec[2] == ref[4] and rec[3] == ref[5]
-    assert [int(r[0]) for r in res["merged"]] == list(range(len(case["out"])))
+    for out, case in ((str(tmp_path / "corpus_words.tsv"), gold["words"][wcase]),
+                      (str(tmp_path / "segments_sos.tsv"), gold["search"][scase])):
+        got = pd.read_csv(out, header=0, sep="\t")
+        assert list(got.columns) == case["columns"] and len(got) == len(case["out"])
+        for a, b in zip(got.values.tolist(), case["out"]):
+            assert all(_same(x, y) for x, y in zip(a, b)), (a, b)
+
+
+def test_row_shards_cover_every_row_once(pkg):
+    pl = importlib.import_module(pkg.__name__ + ".pipelines")
+    sh = importlib.import_module(pkg.__name__ + ".sharding")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "words_traces.json")))
+    records = gold["words"][0]["rows"]
+    costs = pl._row_costs(records)
+    for world in (1, 2, 3, 8):
+        units = sh.assign_units(costs, world)
+        assert sorted(i for u in units for i in u) == list(range(len(records)))
+        loads = [sum(costs[i] for i in u) for u in units]
+        assert max(loads) - min(loads) <= max(costs)
