@@ -2,8 +2,16 @@
 """bench.py -- the reference's headline metric on MI355X (BASELINE.json).
 
 metric : aligned audio hours/sec (CTC DP frames/s), whole job over all N GPUs
-workload: BASELINE.json configs[2] -- synthetic DP-only, 512 segments x 3000 frames x vocab 32
-          (C = 640 label columns, 22 utterances/segment), per GPU (weak scaling).
+workload: --workload synthetic (default) = BASELINE.json configs[2] -- synthetic DP-only, 512 segments
+          x 3000 frames x vocab 32 (C = 640 label columns, 22 utterances/segment), per GPU (weak scaling).
+          The other configurations, DP-only on synthetic emissions (audio and the HF model are not
+          available offline):
+            replay  configs[1]: the recorded window sequence of the reference's 519 s sample file
+                    (183 DP calls, tests/golden/replay_windows.json), --files copies in lockstep, every
+                    round followed by the host read-back the anchor state machine needs;
+            words   configs[3]: 10 000 word-level rows (T ~ U[100,750], 3 or 5 pieces), rows sharded
+                    over the ranks (strong scaling);
+            corpus  configs[4]: 100 h of windows drawn like the replay sequence, sharded over the ranks.
 step   : one pass of the hot path (trellis fill + backtrack + utterance scoring) over that
           batch, inputs resident in HBM when the timed region starts.
 
@@ -32,6 +40,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "replay", "words", "corpus"])
+    ap.add_argument("--files", type=int, default=64, help="replay: audio files advanced in lockstep per GPU")
+    ap.add_argument("--rows", type=int, default=10000, help="words: TSV rows of the whole job")
+    ap.add_argument("--hours", type=float, default=100.0, help="corpus: audio hours of the whole job")
+    ap.add_argument("--per-launch", type=int, default=0, help="words / corpus: segments per launch (0 = 2500 / 2048)")
     ap.add_argument("--segments", type=int, default=512, help="segments per GPU")
     ap.add_argument("--frames", type=int, default=3000)
     ap.add_argument("--vocab", type=int, default=32)
@@ -58,15 +71,256 @@ def parse():
     return ap.parse_args()
 
 
+def roofline_entry(fill_ms, bt_ms, ms_per_step, stride, fill_bytes, step_bytes, default_workload):
+    """The `roofline` object.  `achieved` / `frac` belong to the DOMINANT KERNEL: the fill's own
+    algorithmic bytes (emissions read once, 4TV, + the 1-bit-per-cell trace written once, TC/8) over the
+    fill's own average launch duration.  `step_*` is the whole step: SURVEY section 8(d)'s per-segment figure
+    (the backtrack's 4T + 8C + 4T included) over the step time.  `traffic` = HBM bytes per launch from
+    the PMC counters (tools/collect_traffic.sh, separate --pmc passes, FETCH_SIZE x 2 on gfx950),
+    fill and backtrack kernels, committed under profiles/ for the default workload."""
+    import glob
+    fill_s = float(np.mean(fill_ms)) * 1e-3
+    achieved = fill_bytes / fill_s / 1e9
+    step_achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
+    traffic, src, detail = None, None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if files and default_workload:
+        try:
+            j = json.load(open(files[-1]))
+            fill_t = j["fill_kernel"]["hbm_bytes_per_launch"]
+            bt_t = j.get("backtrack_kernel", {}).get("hbm_bytes_per_launch")
+            traffic = fill_t
+            detail = {"fill_kernel": fill_t, "backtrack_kernel": bt_t,
+                      "fill_vs_fill_algorithmic": fill_t / fill_bytes,
+                      "step_vs_step_algorithmic": ((fill_t + bt_t) / step_bytes) if bt_t else None,
+                      "schedule": j.get("schedule")}
+            src = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 FETCH x2)"
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": detail, "traffic_source": src,
+            "algorithmic_bytes_per_launch": fill_bytes,
+            "algorithmic_bytes_note": "fill kernel only: 4TV + TC/8 per segment (the whole step, backtrack included: step_algorithmic_bytes)",
+            "kernel_ms_avg": float(np.mean(fill_ms)), "kernel_ms_min": float(np.min(fill_ms)),
+            "kernel_ms_samples": int(len(fill_ms)),
+            "kernel_ms_sampling": f"HIP events around every {stride}-th launch of the timed region",
+            "backtrack_kernel_ms_avg": float(np.mean(bt_ms)),
+            "step_algorithmic_bytes": step_bytes, "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS}
+
+
+def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
+    """--workload replay | words | corpus: launches of ragged segments ("groups"); a step is one pass
+    over all groups of this rank."""
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    syn = pkg.synthetic
+    V = args.vocab
+    calls = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_windows.json")))["calls"]
+    sequential = False
+    if args.workload == "replay":
+        # every round = one DP call of the recorded sequence for `files` files in lockstep (weak scaling:
+        # `files` per GPU); the next round needs this round's scores on the host (anchor state machine)
+        base = syn.make_windows_like(calls, V, seed=rank)
+        groups = [[b] * args.files for b in base if len(b[1]) <= b[0].shape[0]]
+        sequential, scaling = True, "weak"
+        name = ("BASELINE.json configs[1]: replay of the reference's sample file (519 s, 157 rows -> %d DP calls, "
+                "T %d..%d), %d files in lockstep per GPU, DP-only on synthetic emissions"
+                % (len(groups), min(c["T"] for c in calls), max(c["T"] for c in calls), args.files))
+    elif args.workload == "words":
+        rows = syn.make_word_rows(args.rows, V)
+        costs = [s[0].shape[0] * len(s[1]) for s in rows]
+        mine = pkg.sharding.assign_units(costs, world)[rank]
+        segs = sorted((rows[i] for i in mine), key=lambda s: -s[0].shape[0] * len(s[1]))
+        per = args.per_launch or 2500
+        groups = [segs[k:k + per] for k in range(0, len(segs), per)]
+        scaling = "strong"
+        name = ("BASELINE.json configs[3]: word-level alignment of %d utterances (T ~ U[100,750], 3 or 5 pieces), "
+                "rows cost-sharded over %d GPU(s), DP-only on synthetic emissions" % (args.rows, world))
+    else:
+        ok = [c for c in calls if c["C"] <= c["T"]]
+        frames_rank = int(args.hours * 3600.0 / INDEX_DURATION / world)
+        drawn = syn.draw_corpus_calls(ok, frames_rank, seed=rank)
+        pool = syn.make_windows_like(drawn[:2048], V, seed=rank)      # 2048 distinct windows, tiled over the share
+        segs = sorted((pool[i % len(pool)] for i in range(len(drawn))), key=lambda s: -s[0].shape[0] * len(s[1]))
+        per = args.per_launch or 2048
+        groups = [segs[k:k + per] for k in range(0, len(segs), per)]
+        scaling = "strong"
+        name = ("BASELINE.json configs[4]: %.0f h corpus as a window stream drawn like the sample file's "
+                "(%d windows on this GPU), sharded over %d GPU(s), DP-only on synthetic emissions"
+                % (args.hours, len(segs), world))
+
+    cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
+    eng = pkg._native.Engine(local_rank)
+    stream = torch.cuda.current_stream()
+    G = []
+    for g in groups:
+        Ts = [s[0].shape[0] for s in g]
+        Cs = [len(s[1]) for s in g]
+        Us = [len(s[2]) - 1 for s in g]
+        plan = eng.plan(cfg.to_native(), V, Ts, Cs, Us, force_cols_per_lane=args.cols_per_lane)
+        uniq = {}
+        for s in g:                      # (replay tiles one window: upload it once per copy all the same)
+            uniq.setdefault(id(s), s)
+        d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in g])).to(dev)
+        d_lab = torch.from_numpy(np.concatenate([s[1] for s in g]).astype(np.int32)).to(dev)
+        d_ub = torch.from_numpy(np.concatenate([s[2] for s in g]).astype(np.int32)).to(dev)
+        nT, nC, nU, B = sum(Ts), sum(Cs), max(1, sum(Us)), len(g)
+        outs = [dict(fol=torch.empty(nC, dtype=torch.int32, device=dev), cp=torch.empty(nT, dtype=torch.float32, device=dev),
+                     seg=torch.empty(3, nU, dtype=torch.float64, device=dev), te=torch.empty(B, dtype=torch.int32, device=dev),
+                     status=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(3)]
+        G.append(dict(plan=plan, lpz=d_lpz, lab=d_lab, ub=d_ub, outs=outs, frames=nT, segs=g, n=0,
+                      host=torch.empty(3, nU, dtype=torch.float64).pin_memory() if sequential else None))
+    frames_step = sum(g["frames"] for g in G)
+    pipelined = not args.serial and not sequential
+
+    def run_group(g):
+        o = g["outs"][g["n"] % 3]
+        g["n"] += 1
+        g["plan"].run_device(g["lpz"].data_ptr(), g["lab"].data_ptr(), g["ub"].data_ptr(), o["fol"].data_ptr(),
+                             o["cp"].data_ptr(), None, o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(),
+                             o["te"].data_ptr(), o["status"].data_ptr(), stream.cuda_stream, pipelined=pipelined)
+        if sequential:   # the state machine reads this round's scores before it can form the next window
+            g["host"].copy_(o["seg"], non_blocking=True)
+            stream.synchronize()
+
+    def step():
+        for g in G:
+            run_group(g)
+
+    def drain():
+        if pipelined:
+            for g in G:
+                g["plan"].flush(stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    spin_budget = 0.3   # seconds of untimed load: clock ramp from idle (a fixed count per rank: no collectives inside)
+    t0 = time.perf_counter()
+    n_spin = 0
+    while time.perf_counter() - t0 < spin_budget and n_spin < args.spinup_steps:
+        step()
+        torch.cuda.synchronize()
+        n_spin += 1
+    for _ in range(args.warmup):
+        step()
+    drain()
+    barrier()
+    stride = args.timing_stride if args.timing_stride > 0 else (1 if args.steps < 16 else 4)
+    n_timed = min((args.steps + stride - 1) // stride, 256)
+    for g in G:
+        g["plan"].set_timing(max(n_timed, 4))
+        g["plan"].set_timing_stride(stride)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        ft = torch.tensor([float(frames_step)], dtype=torch.float64, device=dev)
+        dist.all_reduce(ft)
+        frames_all = float(ft.item())
+    else:
+        frames_all = float(frames_step)
+    fill_ms = np.zeros(n_timed)
+    bt_ms = np.zeros(n_timed)
+    for g in G:   # per recorded step: the sum over this rank's launches
+        f, b = g["plan"].get_timings(n_timed)
+        fill_ms += f
+        bt_ms += b
+
+    # ---- parity gate on the timed inputs (a sample; the full-size checks are tests/test_hip_workloads.py)
+    parity = None
+    if rank == 0 and not args.no_check:
+        from oracle import oracle_c
+        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
+        checked = 0
+        for g in (G[0], G[len(G) // 2], G[-1]):
+            o = g["outs"][(g["n"] - 1) % 3]
+            status = o["status"].cpu().numpy()
+            assert (status == 0).all(), "non-OK status in the benchmark batch"
+            fol = o["fol"].cpu().numpy()
+            seg = o["seg"].cpu().numpy()
+            co = np.concatenate([[0], np.cumsum([len(s[1]) for s in g["segs"]])])
+            uo = np.concatenate([[0], np.cumsum([len(s[2]) - 1 for s in g["segs"]])])
+            for b in (0, len(g["segs"]) - 1):
+                lpz, gt, ub = g["segs"][b]
+                ref = oracle_c.get_segments(lpz, gt, ub, ocfg)
+                assert np.array_equal(fol[co[b]:co[b + 1]], ref["frame_of_label"]), "frame indices differ from oracle"
+                assert np.allclose(seg[2][uo[b]:uo[b + 1]], ref["seg_score"], rtol=0, atol=1e-4)
+                checked += 1
+        parity = f"{checked} segments == oracle (frames bit-exact, scores<=1e-4)"
+
+    if rank == 0:
+        fps = frames_all * args.steps / dt
+        fill_bytes = sum(4 * s[0].shape[0] * V + s[0].shape[0] * len(s[1]) // 8 for g in G for s in g["segs"])
+        step_bytes = sum(g["plan"].info["algorithmic_bytes"] for g in G)
+        shapes = sorted({(g["plan"].info["cols_per_lane"], g["plan"].info["waves_per_seg"]) for g in G})
+        out = {
+            "metric": "aligned audio hours/sec (CTC DP frames/s)",
+            "value": fps * INDEX_DURATION / 3600.0, "unit": "audio-hours/s", "frames_per_s": fps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "spinup": {"steps": n_spin, "note": "untimed passes (<= 0.3 s) before the warm-up steps: clock ramp from idle"},
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "launches_per_step": len(G), "segments_per_step_this_gpu": sum(len(g["segs"]) for g in G),
+                       "frames_per_step_this_gpu": frames_step, "vocab": V, "tile_shapes_K_W": shapes,
+                       "parallelism": f"unit-sharded x{world}", "parity": parity,
+                       "schedule": ("one launch at a time + host read-back of the scores after every round (the anchor "
+                                    "state machine needs them)" if sequential else
+                                    ("serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"))},
+            "roofline": roofline_entry(fill_ms, bt_ms, dt / args.steps * 1e3, stride, fill_bytes, step_bytes, False),
+            "cpu_baseline": cpu,
+        }
+        out["roofline"]["kernel_ms_note"] = "per step: sum over the step's %d launches" % len(G)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_child(args):
+    """The cpu_baseline leg (oracle on the host cores) runs as a child process BEFORE this process
+    touches the GPU: its all-cores part forks workers, which a HIP-initialised process must not do."""
+    import subprocess
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--workload", args.workload, "--segments", str(args.segments),
+           "--frames", str(args.frames), "--vocab", str(args.vocab), "--utts", str(args.utts), "--utt-len", str(args.utt_len),
+           "--sample", str(args.cpu_sample)]
+    try:
+        out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def main():
     args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        # (build the oracle first: the child only needs the C restatement)
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        cpu = cpu_baseline_child(args)
     import torch
     import __graft_entry__ as ge
 
     pkg = ge.build()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -77,6 +331,8 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.workload != "synthetic":
+        return run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
@@ -224,74 +480,10 @@ def main():
             assert np.allclose(seg[2][b], o["seg_score"], rtol=0, atol=1e-4)
         parity = "3 segments == oracle (frames bit-exact, scores<=1e-4)"
 
-    # ---- CPU baseline: the oracle (kind "port") on a bounded sample, rank 0, N == 1 only ---
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        from oracle import oracle_c
-        ns = min(args.cpu_sample, B)
-        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION)
-        sec, reps = 0.0, 0
-        while sec < 10.0 and reps < 16:   # bounded sample: >= 10 s of CPU work, <= 16 passes
-            dt_cpu, st, _ = oracle_c.time_uniform_batch(lpz[:ns], gt[:ns], ub[:ns], ocfg)
-            sec += dt_cpu
-            reps += 1
-        fps = reps * ns * T / sec
-        cpu = {"value": fps * INDEX_DURATION / 3600.0, "unit": "audio-hours/s", "frames_per_s": fps,
-               "cores": 1, "kind": "port",
-               "sample": f"{reps} pass(es) over {ns} of the {B} benchmark segments ({T} frames x {C} columns), "
-                         f"oracle/ctc_segmentation_oracle.c, single thread, {sec:.1f} s",
-               "host_cores": os.cpu_count()}
-        # SURVEY §8(d)'s baseline definition -- what n_process=1 executes per DP call in the
-        # reference: a compiled fill (the C oracle's fill stands in for the Cython one) followed by
-        # the package's interpreted backtrack and scoring loops (the NumPy twin, laid out like the
-        # package).  A handful of segments is enough: ~0.1 s each.
-        try:
-            from oracle import ctc_segmentation_twin as tw
-            import time as _time
-
-            def _compiled_fill(table, lpz_b, gt_b, offsets, blank, flags):
-                tb, offs, t_end = oracle_c.fill_table(lpz_b, gt_b, table.shape[0], blank, flags)
-                table[...] = tb
-                offsets[...] = offs
-                return t_end, table.shape[1] - 1
-
-            tw_fill, tw.cython_fill_table = tw.cython_fill_table, _compiled_fill
-            conf = tw.CtcSegmentationParameters(index_duration=INDEX_DURATION)
-            k, t0 = 0, _time.perf_counter()
-            while k < min(8, B) and _time.perf_counter() - t0 < 3.0:
-                tim, cps, _ = tw.ctc_segmentation(conf, lpz[k], np.asarray(gt[k]).reshape(-1, 1))
-                tw.determine_utterance_segments(conf, ub[k], cps, tim, [""] * (len(ub[k]) - 1))
-                k += 1
-            sec2 = _time.perf_counter() - t0
-            tw.cython_fill_table = tw_fill
-            cpu["reference_structured"] = {
-                "frames_per_s": k * T / sec2, "value": k * T / sec2 * INDEX_DURATION / 3600.0,
-                "unit": "audio-hours/s", "cores": 1,
-                "sample": f"{k} segments: compiled fill (C oracle) + interpreted backtrack and scoring "
-                          f"(oracle/ctc_segmentation_twin.py), {sec2:.1f} s"}
-        except Exception as exc:  # the headline baseline above does not depend on this
-            cpu["reference_structured"] = {"error": repr(exc)}
-
-    # HBM bytes per launch of the dominant kernel: PMC counters are collected in separate
-    # rocprofv3 --pmc passes (tools/collect_traffic.sh) and committed under profiles/; the
-    # figure is only valid for the default workload it was measured on.
-    traffic, traffic_src = None, None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if files and (B, T, V, U, n) == (512, 3000, 32, 22, 28):
-        try:
-            traffic = json.load(open(files[-1]))["fill_kernel"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 FETCH x2)"
-        except Exception:
-            traffic = None
-
     if rank == 0:
         frames_total = world * B * T * args.steps
         fps = frames_total / dt
         value = fps * INDEX_DURATION / 3600.0
-        fill_avg_s = float(np.mean(fill_ms)) * 1e-3
-        alg = info["algorithmic_bytes"]
-        achieved = alg / fill_avg_s / 1e9
         out = {
             "metric": "aligned audio hours/sec (CTC DP frames/s)",
             "value": value, "unit": "audio-hours/s", "frames_per_s": fps,
@@ -307,12 +499,9 @@ def main():
                        "parallelism": f"segment-sharded x{world}", "parity": parity,
                        "gather": (f"RCCL all-gather of (start, end, score), one per {G} steps" if do_gather else None),
                        "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
-            "roofline": {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
-                         "kernel_ms_avg": float(np.mean(fill_ms)), "kernel_ms_min": float(np.min(fill_ms)),
-                         "kernel_ms_samples": int(len(fill_ms)), "kernel_ms_sampling": f"HIP events around every {stride}-th launch of the timed region",
-                         "backtrack_kernel_ms_avg": float(np.mean(bt_ms))},
+            "roofline": roofline_entry(fill_ms, bt_ms, dt / args.steps * 1e3, stride,
+                                       fill_bytes=B * (4 * T * V + T * C // 8), step_bytes=info["algorithmic_bytes"],
+                                       default_workload=(B, T, V, U, n) == (512, 3000, 32, 22, 28)),
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

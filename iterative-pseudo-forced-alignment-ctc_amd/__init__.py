@@ -5,7 +5,7 @@ Import with ``importlib.import_module("iterative-pseudo-forced-alignment-ctc_amd
 through the root-level alias module ``ipfa_amd``.
 """
 from . import _native, synthetic  # noqa: F401
-from . import anchor, formats, pipelines, text_prep, time_reference  # noqa: F401
+from . import anchor, formats, pipelines, sharding, text_prep, time_reference  # noqa: F401
 from . import ctc_segmentation  # noqa: F401
 from .alignment import CTCSegmentation, CTCSegmentationTask, wav2vec2_frames  # noqa: F401
 from .ctc_segmentation import (CtcSegmentationParameters, prepare_text,  # noqa: F401

@@ -49,6 +49,8 @@ class WavFile:
 
     def load(self, frame_offset, num_frames):
         import torch
+        if num_frames == 0 or num_frames < -1:   # as torchaudio.load: the callers' except branches rely on it
+            raise ValueError("Invalid argument: num_frames must be -1 or greater than 0.")
         with wave.open(self.path, "rb") as w:
             w.setpos(min(max(frame_offset, 0), self.num_frames))
             raw = w.readframes(self.num_frames - frame_offset if num_frames < 0 else num_frames)

@@ -66,3 +66,64 @@ def make_uniform_batch(batch, n_frames, vocab, n_utts, utt_len, seed0=0, blank=0
 
 # BASELINE.json configs[2]: 512 segments x 3000 frames x vocab 32, C = 640 label columns
 CONFIG3 = dict(batch=512, n_frames=3000, vocab=32, n_utts=22, utt_len=28)
+
+
+def make_labels_from_lengths(rng, lengths, vocab, blank=0):
+    """Label sequence for utterances of the given token counts (zero-length utterances allowed, as
+    ``prepare_token_list`` produces them for items that tokenise to nothing)."""
+    gt = [-1]
+    utt_begin = []
+    for n in lengths:
+        if gt[-1] != blank:
+            gt.append(blank)
+        utt_begin.append(len(gt) - 1)
+        ids = rng.integers(1, vocab, size=int(n))
+        if blank != 0:
+            ids = np.where(ids == blank, 0, ids)
+        gt.extend(int(i) for i in ids)
+    if gt[-1] != blank:
+        gt.append(blank)
+    utt_begin.append(len(gt) - 1)
+    return np.asarray(gt, np.int64), np.asarray(utt_begin, np.int64)
+
+
+def make_word_rows(n_rows, vocab=32, seed=0, blank=0):
+    """BASELINE.json configs[3] (align_words.sh over 10 000 utterances): one segment per TSV row,
+    T ~ U[100, 750] frames (2..15 s clips), the sentence cut into 3 or 5 pieces around the wanted word
+    with one-token separators between them (word_level_alignment.py:69-84) -- SURVEY §8(d)."""
+    rng = np.random.default_rng(9100 + seed)
+    segs = []
+    for _ in range(n_rows):
+        T = int(rng.integers(100, 751))
+        pieces = int(rng.choice([3, 5]))
+        budget = max(pieces * 2, min(T // 4, 70))            # label columns stay well below the frame count
+        lens = []
+        for p in range(pieces):
+            lens.append(int(rng.integers(2, max(3, budget // pieces))))
+            lens.append(1)                                     # the "·" separator item
+        gt, ub = make_labels_from_lengths(rng, lens, vocab, blank)
+        segs.append((make_emissions(rng, T, vocab, gt, blank), gt, ub))
+    return segs
+
+
+def make_windows_like(calls, vocab=32, seed=0, blank=0):
+    """Segments with the shapes of recorded DP calls (tests/golden/replay_windows.json entries:
+    ``T`` frames, ``utts`` = tokens per utterance): the anchor iteration's window stream, DP-only."""
+    rng = np.random.default_rng(9200 + seed)
+    segs = []
+    for c in calls:
+        gt, ub = make_labels_from_lengths(rng, c["utts"], vocab, blank)
+        segs.append((make_emissions(rng, int(c["T"]), vocab, gt, blank), gt, ub))
+    return segs
+
+
+def draw_corpus_calls(calls, frames_wanted, seed=0):
+    """BASELINE.json configs[4] (100 h corpus): windows drawn with replacement from a recorded window
+    sequence until they hold ``frames_wanted`` frames."""
+    rng = np.random.default_rng(9300 + seed)
+    out, total = [], 0
+    while total < frames_wanted:
+        c = calls[int(rng.integers(0, len(calls)))]
+        out.append(c)
+        total += int(c["T"])
+    return out

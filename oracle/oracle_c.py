@@ -161,3 +161,40 @@ def time_uniform_batch(lpz, gt, utt_begin, cfg=None):
     return dt, status, dict(frame_of_label=fol.reshape(B, C), char_probs=char_probs.reshape(B, T),
                             t_end=t_end, seg_start=seg[0].reshape(B, U), seg_end=seg[1].reshape(B, U),
                             seg_score=seg[2].reshape(B, U))
+
+
+def time_ragged_batch(segs, cfg=None):
+    """Time the C oracle on a ragged batch ``[(lpz [T,V] f32, gt [C] i64, utt_begin [U+1] i64), ...]``:
+    one call into C for the whole batch.  Returns (seconds, status[B]).  Used by the cpu_baseline leg."""
+    import time
+
+    cfg = cfg or make_config()
+    B = len(segs)
+    V = int(segs[0][0].shape[1])
+    Ts = np.asarray([s[0].shape[0] for s in segs], np.int32)
+    Cs = np.asarray([len(s[1]) for s in segs], np.int32)
+    Us = np.asarray([len(s[2]) - 1 for s in segs], np.int32)
+    lpz = np.ascontiguousarray(np.concatenate([np.asarray(s[0], np.float32).reshape(-1) for s in segs]))
+    gt = np.ascontiguousarray(np.concatenate([np.asarray(s[1], np.int64).reshape(-1) for s in segs]))
+    ub = np.ascontiguousarray(np.concatenate([np.asarray(s[2], np.int64).reshape(-1) for s in segs]))
+    lpz_off = np.concatenate([[0], np.cumsum(Ts.astype(np.int64) * V)])[:-1].astype(np.int64)
+    gt_off = np.concatenate([[0], np.cumsum(Cs.astype(np.int64))])[:-1].astype(np.int64)
+    utt_off = np.concatenate([[0], np.cumsum(Us.astype(np.int64))])[:-1].astype(np.int64)
+    nT, nC, nU = int(Ts.sum()), int(Cs.sum()), max(1, int(Us.sum()))
+    timings = np.zeros(nC)
+    char_probs = np.zeros(nT)
+    state = np.zeros(nT, np.int32)
+    fol = np.zeros(nC, np.int32)
+    t_end = np.zeros(B, np.int64)
+    seg = np.zeros((3, nU))
+    status = np.zeros(B, np.int32)
+    t0 = time.perf_counter()
+    lib().oracle_get_segments_batch(
+        ctypes.byref(cfg), ctypes.c_int64(B), _p(lpz, ctypes.c_float), _p(lpz_off, ctypes.c_int64),
+        _p(Ts, ctypes.c_int32), ctypes.c_int64(V), _p(gt, ctypes.c_int64), _p(gt_off, ctypes.c_int64),
+        _p(Cs, ctypes.c_int32), ctypes.c_int64(1), _p(ub, ctypes.c_int64),
+        _p(utt_off, ctypes.c_int64), _p(Us, ctypes.c_int32), _p(timings, ctypes.c_double),
+        _p(char_probs, ctypes.c_double), _p(state, ctypes.c_int32), _p(fol, ctypes.c_int32),
+        _p(t_end, ctypes.c_int64), _p(seg[0], ctypes.c_double), _p(seg[1], ctypes.c_double),
+        _p(seg[2], ctypes.c_double), _p(status, ctypes.c_int32))
+    return time.perf_counter() - t0, status

@@ -138,3 +138,40 @@ def test_batched_device_emissions_feed_the_dp(pkg, oracle):
         assert np.array_equal(a["timings"], o["timings"]) and np.array_equal(a["char_probs"], o["char_probs"])
         assert [s[:2] for s in a["segments"]] == [s[:2] for s in o["segments"]]
         np.testing.assert_allclose([s[2] for s in a["segments"]], [s[2] for s in o["segments"]], rtol=0, atol=1e-4)
+
+
+def test_benedetti_full_file_replay_hip_equals_oracle(pkg, oracle):
+    """BASELINE.json configs[1]: all 157 rows of the reference's sample file (519 s) through the
+    anchor iteration -- the HIP engine against the oracle answering the same requests, and the DP-call
+    sequence against the committed fixture that ``bench.py --workload replay`` times."""
+    import json
+    import os
+
+    from tests.replay_common import REPLAY_AUDIO_SECONDS, REPLAY_PARAMS, NoiseAudio as ReplayAudio, replay_vad
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    rows = json.load(open(os.path.join(gold, "benedetti_rows.json")))["rows"]
+    recorded = json.load(open(os.path.join(gold, "replay_windows.json")))
+    assert len(rows) == 157
+    anchor = importlib.import_module(pkg.__name__ + ".anchor")
+    asr = FakeASR(seed=5, sharp=6.0)
+
+    def run(aligner):
+        calls = []
+        inner = aligner.get_segments_batch
+
+        def recording(tasks, raise_errors=False):
+            calls.extend((int(t.lpz.shape[0]), int(len(t.ground_truth_mat))) for t in tasks)
+            return inner(tasks, raise_errors)
+        aligner.get_segments_batch = recording
+        co = anchor.file_alignment(asr, ReplayAudio(REPLAY_AUDIO_SECONDS, 2024), rows[0]["Sample_Path"],
+                                   [dict(r) for r in rows], replay_vad(), 320.0, anchor.AnchorParams(**REPLAY_PARAMS))
+        return anchor.run_batched([co], aligner)[0], calls
+
+    mk = lambda: pkg.CTCSegmentation(asr, kaldi_style_text=False, time_stamps="fixed", scoring_length=30)
+    hip, hip_calls = run(mk())
+    ref, ref_calls = run(oracle_backed(mk(), oracle))
+    assert hip_calls == ref_calls == [(c["T"], c["C"]) for c in recorded["calls"]]
+    assert len(hip) == len(ref) == recorded["n_result_rows"]
+    for a, b in zip(hip, ref):
+        assert a[:6] == b[:6] and a[7:] == b[7:]
+        assert abs(a[6] - b[6]) <= 1e-4 + 1e-9
