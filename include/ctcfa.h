@@ -166,6 +166,19 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
                       float* char_prob, int32_t* state, double* seg_start, double* seg_end,
                       double* seg_score, int32_t* t_end, int32_t* status);
 
+/*
+ * Same call with the EMISSIONS ALREADY ON THE DEVICE (d_lpz: fp32, segments back to back) and
+ * everything else in host memory: what `get_segments` costs when `get_lpz` left the encoder output in
+ * HBM (alignment.py, keep_lpz_on_device) -- no emission upload, one packed upload of the small inputs,
+ * one result download.  `stream` is the hipStream_t the emissions were produced on (NULL = the null
+ * stream); the call enqueues there and returns when the results are in the host buffers.
+ */
+int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                               const int32_t* T, const int32_t* C, const int32_t* U, const float* d_lpz,
+                               const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label,
+                               float* char_prob, int32_t* state, double* seg_start, double* seg_end,
+                               double* seg_score, int32_t* t_end, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ EXPORTS = (
     "ctcfa_last_error", "ctcfa_default_params", "ctcfa_plan_create", "ctcfa_plan_destroy",
     "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_run_pipelined", "ctcfa_plan_flush",
     "ctcfa_plan_get_timings",
-    "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch",
+    "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch", "ctcfa_align_batch_resident",
 )
 
 
@@ -101,6 +101,8 @@ def load():
     lib.ctcfa_plan_set_timing_stride.argtypes = [vp, ctypes.c_int]
     lib.ctcfa_align_batch.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
                                       i32p, i32p, i32p] + [vp] * 11
+    lib.ctcfa_align_batch_resident.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
+                                               i32p, i32p, i32p] + [vp] * 12
     _lib = lib
     return lib
 
@@ -157,19 +159,23 @@ class Engine:
             exc = NotImplementedError if rc == ERR_UNSUPPORTED else (ValueError if rc == ERR_INVALID else NativeLibraryError)
             raise exc(f"{what} failed ({rc}): {msg}")
 
-    def align_batch(self, params, lpz_list, labels_list, utt_begin_list=None, want_state=True):
-        """Host-buffer entry ``ctcfa_align_batch``.
+    def align_batch(self, params, lpz_list, labels_list, utt_begin_list=None, want_state=True, d_lpz=None,
+                    stream=None, shapes=None):
+        """Host-buffer entry ``ctcfa_align_batch``, or -- with ``d_lpz`` (device address of the
+        concatenated fp32 emissions) and ``shapes`` = [(T_b, V), ...] -- ``ctcfa_align_batch_resident``.
 
         lpz_list: fp32 [T_b, V]; labels_list: int [C_b] (ground_truth_mat[:, 0]);
-        utt_begin_list: int [U_b + 1] or None.  Returns a dict of concatenated outputs plus
-        per-segment views.
+        utt_begin_list: int [U_b + 1] or None.  Returns a list of per-segment dicts.
         """
-        B = len(lpz_list)
-        V = int(lpz_list[0].shape[1])
-        T = _i32([l.shape[0] for l in lpz_list])
+        shapes = shapes or [l.shape for l in lpz_list]
+        B = len(shapes)
+        V = int(shapes[0][1])
+        T = _i32([sh[0] for sh in shapes])
         C = _i32([len(g) for g in labels_list])
-        lpz = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in lpz_list]))
-        labels = _i32(np.concatenate([np.asarray(g).reshape(-1) for g in labels_list]))
+        if d_lpz is None:
+            lpz = lpz_list[0].reshape(-1) if B == 1 else np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in lpz_list])
+            lpz = np.ascontiguousarray(lpz, dtype=np.float32)
+        labels = _i32(labels_list[0]) if B == 1 else _i32(np.concatenate([np.asarray(g).reshape(-1) for g in labels_list]))
         have_utt = utt_begin_list is not None
         U = _i32([len(u) - 1 for u in utt_begin_list]) if have_utt else None
         ub = _i32(np.concatenate([np.asarray(u).reshape(-1) for u in utt_begin_list])) if have_utt else None
@@ -181,12 +187,18 @@ class Engine:
         seg = np.zeros((3, max(nU, 1)), np.float64) if have_utt else None
         t_end = np.zeros(B, np.int32)
         status = np.zeros(B, np.int32)
-        rc = self._lib.ctcfa_align_batch(
-            self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U), _ptr(lpz), _ptr(labels),
-            _ptr(ub), _ptr(fol), _ptr(cp), _ptr(state),
-            _ptr(seg[0]) if have_utt else None, _ptr(seg[1]) if have_utt else None,
-            _ptr(seg[2]) if have_utt else None, _ptr(t_end), _ptr(status))
-        self._check(rc, "ctcfa_align_batch")
+        tail = (_ptr(labels), _ptr(ub), _ptr(fol), _ptr(cp), _ptr(state),
+                _ptr(seg[0]) if have_utt else None, _ptr(seg[1]) if have_utt else None,
+                _ptr(seg[2]) if have_utt else None, _ptr(t_end), _ptr(status))
+        if d_lpz is None:
+            rc = self._lib.ctcfa_align_batch(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
+                                             _ptr(lpz), *tail)
+            self._check(rc, "ctcfa_align_batch")
+        else:
+            rc = self._lib.ctcfa_align_batch_resident(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
+                                                      ctypes.c_void_p(int(d_lpz)), *tail,
+                                                      ctypes.c_void_p(stream) if stream else None)
+            self._check(rc, "ctcfa_align_batch_resident")
         t_off = np.concatenate([[0], np.cumsum(T)])
         c_off = np.concatenate([[0], np.cumsum(C)])
         u_off = np.concatenate([[0], np.cumsum(U)]) if have_utt else None

@@ -36,7 +36,12 @@ struct ctcfa_engine {
     int lds_limit = 160 * 1024;
     int num_cu = 256;
     ScratchSlot scratch[kNumSlots];
-    std::vector<unsigned char> host_out;  // staging for the single result download of ctcfa_align_batch
+    // pinned staging of the host-buffer entries: ONE packed upload (role table, segment table, labels,
+    // utterance starts) and ONE result download per call
+    unsigned char* h_in = nullptr;
+    size_t h_in_cap = 0;
+    unsigned char* h_out = nullptr;
+    size_t h_out_cap = 0;
 };
 
 struct ctcfa_plan {
@@ -353,6 +358,8 @@ void ctcfa_engine_destroy(ctcfa_engine* eng) {
     if (!eng) return;
     for (auto& sl : eng->scratch)
         if (sl.p) (void)hipFree(sl.p);
+    if (eng->h_in) (void)hipHostFree(eng->h_in);
+    if (eng->h_out) (void)hipHostFree(eng->h_out);
     if (eng->stream) (void)hipStreamDestroy(eng->stream);
     delete eng;
 }
@@ -614,16 +621,13 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         }                                                                                     \
     } while (0)
     if (use_scratch) {
+        // transient plan of a host-buffer call: workspace from the engine's grow-only scratch; the role and
+        // segment tables travel in the caller's packed upload (align_impl sets d_roles / d_segs)
         pl->scratch_owned = true;
-        PLAN_TRY(scratch_get(eng, kSlotRoles, reinterpret_cast<void**>(&pl->d_roles), sizeof(ctcfa::FillRoles)));
-        PLAN_TRY(scratch_get(eng, kSlotSegs, reinterpret_cast<void**>(&pl->d_segs), sizeof(SegDesc) * (size_t)batch));
         PLAN_TRY(scratch_get(eng, kSlotBits, reinterpret_cast<void**>(&pl->d_bits[0]),
                              sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
         PLAN_TRY(scratch_get(eng, kSlotLastcol, reinterpret_cast<void**>(&pl->d_lastcol[0]),
                              sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
-        PLAN_TRY(hipMemcpyAsync(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice, eng->stream));
-        PLAN_TRY(hipMemcpyAsync(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice,
-                                eng->stream));
     } else {
         PLAN_TRY(hipMalloc(&pl->d_roles, sizeof(ctcfa::FillRoles)));
         PLAN_TRY(hipMemcpy(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice));
@@ -893,14 +897,28 @@ int ctcfa_plan_get_timings(ctcfa_plan* pl, int n, float* fill_ms, float* backtra
     return CTCFA_OK;
 }
 
-int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
-                      const int32_t* T, const int32_t* C, const int32_t* U, const float* lpz,
-                      const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label,
-                      float* char_prob, int32_t* state, double* seg_start, double* seg_end,
-                      double* seg_score, int32_t* t_end, int32_t* status) {
-    if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
-    if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
-        return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
+namespace {
+
+hipError_t pinned_get(unsigned char** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(p), want, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+// One synchronous alignment call on the engine's stream (or the caller's): transient plan, ONE packed
+// upload of the small inputs, the emissions uploaded (host_lpz) or used where they are (dev_lpz), both
+// kernels, ONE result download.  An anchor iteration issues hundreds of such calls for windows of a
+// few hundred frames: what a call costs beyond its kernels is what this function keeps small.
+int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab, const int32_t* T,
+               const int32_t* C, const int32_t* U, const float* host_lpz, const float* dev_lpz, hipStream_t st,
+               const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label, float* char_prob,
+               int32_t* state, double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
+               int32_t* status) {
     DeviceGuard on_device(eng->device);
     ctcfa_plan* pl = nullptr;
     int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true);
@@ -908,7 +926,6 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
     const size_t n_lpz = (size_t)pl->total_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
     const size_t n_utt = (size_t)pl->total_U, n_ub = n_utt + batch;
-    hipStream_t st = eng->stream;
     auto cleanup = [&]() {  // the buffers are the engine's scratch; quiesce before the next call reuses them
         (void)hipStreamSynchronize(st);
         ctcfa_plan_destroy(pl);
@@ -922,25 +939,29 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
             return set_err(eng, CTCFA_ERR_HIP, m);                                        \
         }                                                                                 \
     } while (0)
-    // Device layout: emissions on their own; the small inputs (labels, utt_begin) in ONE upload;
-    // every result array in ONE block that comes back with ONE download (a copy call costs ~10 us,
-    // more than the kernels of a 10 s window).
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t in_lab = 0, in_ub = up(n_lab * 4), in_bytes = in_ub + (want_seg ? up(n_ub * 4) : 0);
+    // packed upload: role table | segment table | labels | utterance starts
+    const size_t in_roles = 0, in_segs = up(sizeof(ctcfa::FillRoles)), in_lab = in_segs + up(sizeof(SegDesc) * (size_t)batch),
+                 in_ub = in_lab + up(n_lab * 4), in_bytes = in_ub + (want_seg ? up(n_ub * 4) : 0);
     const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
                  o_tend = o_state + (state ? up(n_frm * 4) : 0), o_status = o_tend + up((size_t)batch * 4),
                  o_seg = o_status + up((size_t)batch * 4), out_bytes = o_seg + (want_seg ? up(3 * n_utt * 8) : 0);
-    float* d_lpz = nullptr;
+    float* d_lpz = const_cast<float*>(dev_lpz);
     unsigned char *d_in = nullptr, *d_out = nullptr;
-    AB_TRY(scratch_get(eng, kSlotLpz, reinterpret_cast<void**>(&d_lpz), n_lpz * sizeof(float)));
+    if (!d_lpz) AB_TRY(scratch_get(eng, kSlotLpz, reinterpret_cast<void**>(&d_lpz), n_lpz * sizeof(float)));
     AB_TRY(scratch_get(eng, kSlotIn, reinterpret_cast<void**>(&d_in), in_bytes));
     AB_TRY(scratch_get(eng, kSlotOut, reinterpret_cast<void**>(&d_out), out_bytes));
-    if (eng->host_out.size() < std::max(in_bytes, out_bytes)) eng->host_out.resize(std::max(in_bytes, out_bytes) * 5 / 4 + 256);
-    unsigned char* h = eng->host_out.data();
+    AB_TRY(pinned_get(&eng->h_in, &eng->h_in_cap, in_bytes));
+    AB_TRY(pinned_get(&eng->h_out, &eng->h_out_cap, out_bytes));
+    unsigned char* h = eng->h_in;
+    std::memcpy(h + in_roles, &pl->roles, sizeof(ctcfa::FillRoles));
+    std::memcpy(h + in_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch);
     std::memcpy(h + in_lab, labels, n_lab * 4);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
     AB_TRY(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, st));
-    AB_TRY(hipMemcpyAsync(d_lpz, lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
+    if (host_lpz) AB_TRY(hipMemcpyAsync(d_lpz, host_lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
+    pl->d_roles = reinterpret_cast<ctcfa::FillRoles*>(d_in + in_roles);
+    pl->d_segs = reinterpret_cast<SegDesc*>(d_in + in_segs);
     int32_t* d_lab = reinterpret_cast<int32_t*>(d_in + in_lab);
     int32_t* d_ub = want_seg ? reinterpret_cast<int32_t*>(d_in + in_ub) : nullptr;
     double* d_seg = want_seg ? reinterpret_cast<double*>(d_out + o_seg) : nullptr;
@@ -953,22 +974,48 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
         cleanup();
         return rc;
     }
-    // the staging block h is reused for the download: wait until the upload and the kernels are done
+    unsigned char* ho = eng->h_out;
+    AB_TRY(hipMemcpyAsync(ho, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     AB_TRY(hipStreamSynchronize(st));
-    AB_TRY(hipMemcpy(h, d_out, out_bytes, hipMemcpyDeviceToHost));
-    std::memcpy(frame_of_label, h + o_fol, n_lab * 4);
-    std::memcpy(char_prob, h + o_cp, n_frm * 4);
-    if (state) std::memcpy(state, h + o_state, n_frm * 4);
-    std::memcpy(t_end, h + o_tend, (size_t)batch * 4);
-    std::memcpy(status, h + o_status, (size_t)batch * 4);
+    std::memcpy(frame_of_label, ho + o_fol, n_lab * 4);
+    std::memcpy(char_prob, ho + o_cp, n_frm * 4);
+    if (state) std::memcpy(state, ho + o_state, n_frm * 4);
+    std::memcpy(t_end, ho + o_tend, (size_t)batch * 4);
+    std::memcpy(status, ho + o_status, (size_t)batch * 4);
     if (want_seg) {
-        std::memcpy(seg_start, h + o_seg, n_utt * 8);
-        std::memcpy(seg_end, h + o_seg + n_utt * 8, n_utt * 8);
-        std::memcpy(seg_score, h + o_seg + 2 * n_utt * 8, n_utt * 8);
+        std::memcpy(seg_start, ho + o_seg, n_utt * 8);
+        std::memcpy(seg_end, ho + o_seg + n_utt * 8, n_utt * 8);
+        std::memcpy(seg_score, ho + o_seg + 2 * n_utt * 8, n_utt * 8);
     }
 #undef AB_TRY
     ctcfa_plan_destroy(pl);
     return CTCFA_OK;
+}
+
+}  // namespace
+
+int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                      const int32_t* T, const int32_t* C, const int32_t* U, const float* lpz,
+                      const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label,
+                      float* char_prob, int32_t* state, double* seg_start, double* seg_end,
+                      double* seg_score, int32_t* t_end, int32_t* status) {
+    if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
+    if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
+    return align_impl(eng, params, batch, vocab, T, C, U, lpz, nullptr, eng->stream, labels, utt_begin, frame_of_label,
+                      char_prob, state, seg_start, seg_end, seg_score, t_end, status);
+}
+
+int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                               const int32_t* T, const int32_t* C, const int32_t* U, const float* d_lpz,
+                               const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label,
+                               float* char_prob, int32_t* state, double* seg_start, double* seg_end,
+                               double* seg_score, int32_t* t_end, int32_t* status, void* stream) {
+    if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
+    if (!d_lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL buffer");
+    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, d_lpz, reinterpret_cast<hipStream_t>(stream), labels,
+                      utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
 }
 
 }  // extern "C"

@@ -45,6 +45,9 @@
 #ifndef CTCFA_TILE_PRIO
 #define CTCFA_TILE_PRIO 4
 #endif
+#ifndef CTCFA_VGPR_CAP
+#define CTCFA_VGPR_CAP 1
+#endif
 #ifndef CTCFA_PF
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
 #endif
@@ -164,7 +167,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // dynamic LDS = NS slots * kRows * (VP+2) * 8  +  exchange rings  +  last-column ring + counters.
 // ---------------------------------------------------------------------------------------
 template <int K, int VP, bool CK = false>
-__global__ void __attribute__((amdgpu_waves_per_eu(((K <= 2 || (K == 3 && CK)) && VP <= 64) ? 8 : 1)))   // narrow tiles: 64 VGPRs, room for the backtrack beside it
+__global__ void __attribute__((amdgpu_waves_per_eu(((K <= 2 || (K == 3 && CK)) && VP <= 64 && CTCFA_VGPR_CAP) ? 8 : 1)))   // narrow tiles: 64 VGPRs, room for the backtrack beside it
 __launch_bounds__((K >= 10) ? 320 : (K >= 8) ? 512 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
@@ -351,6 +354,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             };
             if constexpr (VP == 32) {   // two register sets: loads run a block ahead of the LDS writes
+                // (a third set -- loads two blocks ahead -- measured no faster, and does not fit the
+                // 64-register budget of the narrow tiles)
                 float4 ea[NP], eb[NP];
                 vload(0, ea);
                 for (int jb = 0; jb < nblk; jb += 2) {

@@ -241,54 +241,18 @@ def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, eng
 
 
 def _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state):
-    """Device-resident emissions: plan + ctcfa_plan_run_device on the current torch stream."""
+    """Device-resident emissions (torch CUDA tensors): ``ctcfa_align_batch_resident`` on the current
+    torch stream -- the emissions are used where they are, the small inputs go up in one packed copy,
+    the results come back in one; no per-call device allocation."""
     import torch
 
     dev = lpz_list[0].device
-    T = [int(l.shape[0]) for l in lpz_list]
-    V = int(lpz_list[0].shape[1])
-    C = [len(g) for g in labels]
-    have_utt = utt_begin_list is not None
-    U = [len(u) - 1 for u in utt_begin_list] if have_utt else None
-    plan = engine.plan(config.to_native(), V, T, C, U)
-    try:
-        d_lpz = torch.cat([l.reshape(-1).to(torch.float32) for l in lpz_list]).contiguous()
-        d_lab = torch.from_numpy(np.concatenate(labels).astype(np.int32)).to(dev)
-        nT, nC, nU = sum(T), sum(C), (sum(U) if have_utt else 0)
-        B = len(T)
-        d_ub = torch.from_numpy(np.concatenate([np.asarray(u, np.int32) for u in utt_begin_list])).to(dev) if have_utt else None
-        d_fol = torch.empty(nC, dtype=torch.int32, device=dev)
-        d_cp = torch.empty(nT, dtype=torch.float32, device=dev)
-        d_st = torch.empty(nT, dtype=torch.int32, device=dev) if want_state else None
-        d_seg = torch.empty(3, max(nU, 1), dtype=torch.float64, device=dev) if have_utt else None
-        d_te = torch.empty(B, dtype=torch.int32, device=dev)
-        d_status = torch.empty(B, dtype=torch.int32, device=dev)
-        ptr = lambda t: t.data_ptr() if t is not None else None
-        plan.run_device(ptr(d_lpz), ptr(d_lab), ptr(d_ub), ptr(d_fol), ptr(d_cp), ptr(d_st),
-                        ptr(d_seg[0]) if have_utt else None, ptr(d_seg[1]) if have_utt else None,
-                        ptr(d_seg[2]) if have_utt else None, ptr(d_te), ptr(d_status),
-                        torch.cuda.current_stream(dev).cuda_stream)
-        fol, cp = d_fol.cpu().numpy(), d_cp.cpu().numpy()   # .cpu() synchronises with the stream
-        st = d_st.cpu().numpy() if want_state else None
-        seg = d_seg.cpu().numpy() if have_utt else None
-        te, status = d_te.cpu().numpy(), d_status.cpu().numpy()
-    finally:
-        plan.close()
-    t_off = np.concatenate([[0], np.cumsum(T)])
-    c_off = np.concatenate([[0], np.cumsum(C)])
-    u_off = np.concatenate([[0], np.cumsum(U)]) if have_utt else None
-    out = []
-    for b in range(B):
-        d = dict(status=int(status[b]), t_end=int(te[b]), frame_of_label=fol[c_off[b]:c_off[b + 1]],
-                 char_prob=cp[t_off[b]:t_off[b + 1]])
-        if want_state:
-            d["state"] = st[t_off[b]:t_off[b + 1]]
-        if have_utt:
-            d["seg_start"] = seg[0][u_off[b]:u_off[b + 1]]
-            d["seg_end"] = seg[1][u_off[b]:u_off[b + 1]]
-            d["seg_score"] = seg[2][u_off[b]:u_off[b + 1]]
-        out.append(d)
-    return out
+    shapes = [(int(l.shape[0]), int(l.shape[1])) for l in lpz_list]
+    flat = [l.reshape(-1) if l.dtype == torch.float32 and l.is_contiguous() else l.to(torch.float32).contiguous().reshape(-1)
+            for l in lpz_list]
+    d_lpz = flat[0] if len(flat) == 1 else torch.cat(flat)   # (one window: no copy at all)
+    return engine.align_batch(config.to_native(), None, labels, utt_begin_list, want_state=want_state,
+                              d_lpz=d_lpz.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream, shapes=shapes)
 
 
 def ctc_segmentation(config, lpz, ground_truth, engine=None):

@@ -10,6 +10,8 @@ pkg = ge.build()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 syn = pkg.synthetic
 B, T, V, U, n = 512, 3000, 32, 22, 28
+if len(sys.argv) > 5:
+    B, T, U, n = (int(x) for x in sys.argv[2:6])
 lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n)
 C = gt.shape[1]
 cfg = pkg.CtcSegmentationParameters(index_duration=0.02)
@@ -30,11 +32,12 @@ for _ in range(300):
                     d_seg[0].data_ptr(), d_seg[1].data_ptr(), d_seg[2].data_ptr(), d_te.data_ptr(),
                     d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-raw = d_cp.cpu().numpy().view(np.uint64)[: 64 * 16 * 8].reshape(64, 16, 8).astype(np.int64)
+nb = min(B, 64)
+raw = d_cp.cpu().numpy().view(np.uint64)[: nb * 16 * 8].reshape(nb, 16, 8).astype(np.int64)
 for w in range(W):
     r = raw[:, w, :]
     print(f"tile {w}: total {np.median(r[:,0]):.0f} cyc  nbr-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  "
-          f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  blocks {np.median(r[:,5]):.0f}..{np.median(r[:,6]):.0f}  "
+          f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  in-rows {np.median(r[:,5]):.0f}  last block {np.median(r[:,6]):.0f}  "
           f"start +{np.median(r[:,7]-raw[:,0,7]):.0f}")
 r = raw[:, 15, :]
 print(f"producer: total {np.median(r[:,0]):.0f} cyc  space-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  load-wait + write {np.median(r[:,2]):.0f}  blocks {np.median(r[:,4]):.0f}")
