@@ -242,7 +242,7 @@ int vgprs_of(int K, bool ckpt) {  // compiled register counts, rounded up to the
         default: return 256;
     }
 }
-constexpr int kBacktrackVgprs = 104;   // backtrack_kernel<*>: 92..97 registers
+constexpr int kBacktrackVgprs = 96;   // backtrack_kernel<*>: __launch_bounds__(256, 5)
 
 bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_cu, int force_k, int nprod,
                 bool ckpt, ShapeChoice* out) {
@@ -287,6 +287,10 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
         if (act_cu + 8 > 32 || vgprs_of(K, ckpt) * ((act_cu + 3) / 4) + 2 * kBacktrackVgprs > 512 ||
             g_eff * r512(lds) + 2 * r512(lds_beside) > lds_limit)
             cost *= 1.25;
+        // Many coupled tiles are fragile beside another kernel: a tile that loses its issue slots to a
+        // backtrack wave holds up every tile to its right (measured: 8 tiles, decision-word mode, +44 % beside
+        // the backtrack, 4 tiles +0 %).  In checkpoint mode the backtrack steps back instead (bt_low_prio).
+        if (!ckpt && W > 6) cost *= 1.25;
         cost += 1e-3 * waves_per_wg;
         if (best_cost < 0.0 || cost < best_cost) {
             best_cost = cost;
@@ -757,6 +761,10 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.blank = pl->prm.blank;
     bp.Cpad = pl->roles.cpad;
     bp.flags = pl->prm.flags;
+    // Eight or more coupled fill tiles per segment: the (heavier, checkpoint-mode) backtrack of the previous
+    // batch runs below them instead of above (512 x 1242: 0.362 -> 0.313 ms per step; with six tiles or
+    // fewer the backtrack is what a step waits for and keeps its priority)
+    if (pl->ckpt && pl->W >= 8) bp.flags |= ctcfa::kBtFlagLowPriority;
     bp.L = pl->prm.score_min_mean_over_L;
     bp.rec_bytes = pl->rec_bytes;
     bp.lab_bytes = pl->lab_bytes;

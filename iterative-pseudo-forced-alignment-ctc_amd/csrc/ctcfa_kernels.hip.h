@@ -965,6 +965,7 @@ fill_gather_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ l
 // dynamic LDS: rec[nblk] (entry column, switch mask per 32-row block) + char_probs copy [T]
 // ---------------------------------------------------------------------------------------
 constexpr int kBtThreads = 256;
+constexpr uint32_t kBtFlagLowPriority = 0x100u;   // BtParams.flags: run below the fill tiles of the next batch (host decides)
 
 struct BtParams {
     int V, blank, Cpad;
@@ -1240,7 +1241,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 // slot in step jb + 2 (two register sets, by block parity).  Lane v < V stages
                 // vocabulary entry v of its rows, lane V (if there is one) the start column's pseudo
                 // entry; everything under ONE lane mask per block: put + issue have to fit in a step.
-                __builtin_amdgcn_s_setprio(1);
+                if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
                 constexpr int kHalf = kRows / 2;
                 const int r0 = (wave - 2) * kHalf;
                 float e0[kHalf], e1[kHalf];
@@ -1332,7 +1333,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 __builtin_amdgcn_s_setprio(0);
             } else if (wave == 1) {
                 // ======== walker: one v_readlane + four scalar operations per row ====================
-                __builtin_amdgcn_s_setprio(3);
+                if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
                 int x = 0;
                 for (int j = jstart; j >= 0; --j) {
                     lds_barrier();                              // A
@@ -1367,7 +1368,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 }
             } else {
                 // ======== wave 0: recompute =========================================================
-                __builtin_amdgcn_s_setprio(3);
+                if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
                 const uint32_t* seg_bits = bits + sd.bits_off;
                 const bool preamble = (p.flags & 2u) != 0;
                 auto cell = [&](float& prev, uint32_t& dec, float ee, float m) {
@@ -1658,7 +1659,7 @@ struct WaveSync {  // one wave: program order + completed memory operations is a
 };
 
 template <int PB>  // 0: decision words from the fill; 33 / 65: checkpoint mode, V <= 32 / V <= 64
-__global__ void __launch_bounds__(kBtThreads, 4)   // <= 128 VGPRs: two workgroups per CU beside the fill's
+__global__ void __launch_bounds__(kBtThreads, 5)   // <= 96 VGPRs (it wants 97): two backtrack workgroups still fit a SIMD that carries five 64-register fill tiles
 backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_v[kBtThreads / 64];

@@ -807,3 +807,23 @@ def test_serial_call_after_pipelined_calls_waits_for_the_pending_backtrack(pkg, 
         for k in ("status", "te", "fol", "seg"):
             assert torch.equal(o[k], ref[k]), k
     plan.close()
+
+
+def test_one_over_long_text_is_that_segments_status(pkg, oracle, engine):
+    """A segment with more label columns than one fill workgroup covers (> ~5 400) gets status 4 and
+    a NotImplementedError of its own; the other segments of the batch are aligned (the reference would
+    only be slow there; a batch-wide failure would lose every file of a lockstep round)."""
+    syn = pkg.synthetic
+    rng = np.random.default_rng(5)
+    ok = [syn.make_segment(50 + s, 400, 32, 3, 20) for s in range(3)]
+    gt, ub = syn.make_labels(rng, 200, 29, 32)          # 6 002 label columns
+    long_seg = (syn.make_emissions(rng, 7000, 32, gt), gt, ub)
+    short_audio = syn.make_segment(60, 30, 32, 4, 20)   # C > T: status 1, and no part in the launch shape
+    segs = [ok[0], long_seg, ok[1], short_audio, ok[2]]
+    res = _run(pkg, segs)
+    assert [r["status"] for r in res] == [0, 4, 0, 1, 0]
+    _check(pkg, oracle, [segs[i] for i in (0, 2, 4)], [res[i] for i in (0, 2, 4)])
+    with pytest.raises(NotImplementedError):
+        pkg.ctc_segmentation._raise_for_status(res[1]["status"])
+    with pytest.raises(AssertionError):
+        pkg.ctc_segmentation._raise_for_status(res[3]["status"])

@@ -110,3 +110,36 @@ def test_batched_emissions_one_padded_forward(pkg):
     # default frame rule (SpeechBrain's relative lengths) is within one frame of the exact count
     for s, b in zip(singles, al.get_lpz_batch(waves)):
         assert abs(b.shape[0] - s.shape[0]) <= 1
+
+
+def test_inputs_numpy_would_refuse_are_refused_on_the_host(pkg):
+    """Labels and utterance starts reach the kernels as raw indices: what the package's NumPy code
+    would answer with IndexError is refused before any launch (no GPU needed for the refusal)."""
+    cs = pkg.ctc_segmentation
+    lpz = np.zeros((20, 8), np.float32)
+    good = np.array([-1, 0, 3, 4, 0], np.int32)
+    cs._validate_segments([lpz], [good], [np.array([1, 4])])
+    with pytest.raises(IndexError):
+        cs._validate_segments([lpz], [np.array([-1, 0, 8, 0], np.int32)], None)          # label id == V
+    with pytest.raises(IndexError):
+        cs._validate_segments([lpz], [np.array([-1, 0, -3, 0], np.int32)], None)         # negative label
+    with pytest.raises(ValueError):
+        cs._validate_segments([lpz, np.zeros((5, 9), np.float32)], [good, good], None)   # two vocabulary sizes
+    with pytest.raises(ValueError):
+        cs._validate_segments([lpz], [np.array([0, 1, 2], np.int32)], None)              # no leading -1
+    with pytest.raises(IndexError):
+        cs._validate_segments([lpz], [good], [np.array([1, 4, 4])])                      # trailing empty utterance
+    with pytest.raises(IndexError):
+        cs._validate_segments([lpz], [good], [np.array([0, 4])])                         # start column as an utterance start
+
+
+def test_every_task_keeps_its_own_timing_config(pkg):
+    """time_stamps="auto": index_duration = speech_len / lpz_len / fs differs from task to task; tasks
+    prepared up front (run_batched, align_words) must not all see the last one's value."""
+    from tests.fakes import FakeASR
+    al = pkg.CTCSegmentation(FakeASR(seed=1), kaldi_style_text=False, time_stamps="auto")
+    a = al.prepare_segmentation_task(["HOLA"], np.zeros((50, 32), np.float32), "a", 16000)
+    b = al.prepare_segmentation_task(["HOLA"], np.zeros((50, 32), np.float32), "b", 32000)
+    assert a.config is not b.config
+    assert a.config.index_duration == pytest.approx(16000 / 50 / 16000)
+    assert b.config.index_duration == pytest.approx(32000 / 50 / 16000)

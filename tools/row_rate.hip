@@ -20,9 +20,22 @@ __global__ void __launch_bounds__(1024) row_kernel(unsigned long long* cyc, floa
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int PITCH = 34;
     const int lane = threadIdx.x & 63;
+    using lds_vint = volatile __attribute__((address_space(3))) int;
+    lds_vint* flag = (lds_vint*)(smem + 32 * 34 * 8);
+    if (threadIdx.x == 0) *flag = 0;
     float2* s2 = reinterpret_cast<float2*>(smem);
     for (int i = threadIdx.x; i < 32 * PITCH; i += blockDim.x) s2[i] = make_float2(-1.0f - 0.01f * (i % 7), -0.5f);
     __syncthreads();
+    if (MODE >= 4 && threadIdx.x >= 64 && threadIdx.x < 128) {   // a "producer" that has nothing to do: polls a counter in LDS, as wait_space does
+        if (MODE == 4) {
+            while (__builtin_amdgcn_ballot_w64(*flag < 1) != 0ull) __builtin_amdgcn_s_sleep(2);
+        } else {
+            while (__builtin_amdgcn_ballot_w64(*flag < 1) != 0ull) __builtin_amdgcn_s_sleep(100);
+        }
+        return;
+    }
+    if (MODE >= 7 && threadIdx.x >= 128) return;
+    if (MODE == 6 || MODE == 7) __builtin_amdgcn_s_setprio(1);
     float prev[K];
     uint32_t gaddr[K];
 #pragma unroll
@@ -68,11 +81,36 @@ __global__ void __launch_bounds__(1024) row_kernel(unsigned long long* cyc, floa
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (MODE >= 4 && threadIdx.x == 0) *flag = 1;
     float s = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) s += prev[k];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int K, int MODE>
+void run_pair(const int* d_lab) {   // one computing wave + one polling wave per workgroup, one workgroup per CU
+    float* d;
+    unsigned long long* c;
+    (void)hipMalloc(&d, 512 * 1024 * 4);
+    (void)hipMalloc(&c, 512 * 16 * 8);
+    const int blocks = 94;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((row_kernel<K, MODE>), dim3(MODE == 8 ? 1 : 256), dim3(MODE >= 7 ? 256 : 128), MODE >= 7 ? 40960 : 32 * 34 * 8 + 64, 0, c, d, blocks, d_lab);
+        (void)hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> h(256 * 2);
+    (void)hipMemcpy(h.data(), c, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> t;
+    const int nb = MODE == 8 ? 1 : 256, wpb = MODE >= 7 ? 4 : 2;
+    h.resize(nb * wpb);
+    (void)hipMemcpy(h.data(), c, h.size() * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < nb; ++i) t.push_back(h[wpb * i]);
+    std::sort(t.begin(), t.end());
+    printf("K=%d mode=%d (1 computing + 1 polling wave): %6.1f cyc/row\n", K, MODE, (double)t[nb / 2] / (blocks * 32.0));
+    (void)hipFree(d);
+    (void)hipFree(c);
 }
 
 template <int K, int MODE>
@@ -85,9 +123,9 @@ void run(const int* d_lab) {
     printf("K=%d mode=%d:", K, MODE);
     for (int wps : {1, 2, 3, 4}) {   // waves per SIMD: one workgroup of 4*wps waves per CU
         const int nw = 4 * wps;
-        hipLaunchKernelGGL((row_kernel<K, MODE>), dim3(256), dim3(64 * nw), 32 * 34 * 8, 0, c, d, blocks, d_lab);
+        hipLaunchKernelGGL((row_kernel<K, MODE>), dim3(256), dim3(64 * nw), 32 * 34 * 8 + 64, 0, c, d, blocks, d_lab);
         (void)hipDeviceSynchronize();
-        hipLaunchKernelGGL((row_kernel<K, MODE>), dim3(256), dim3(64 * nw), 32 * 34 * 8, 0, c, d, blocks, d_lab);
+        hipLaunchKernelGGL((row_kernel<K, MODE>), dim3(256), dim3(64 * nw), 32 * 34 * 8 + 64, 0, c, d, blocks, d_lab);
         (void)hipDeviceSynchronize();
         std::vector<unsigned long long> h(256 * nw);
         (void)hipMemcpy(h.data(), c, h.size() * 8, hipMemcpyDeviceToHost);
@@ -110,5 +148,7 @@ int main() {
     run<2, 1>(d_lab); run<3, 1>(d_lab);
     run<2, 2>(d_lab); run<3, 2>(d_lab);
     run<2, 3>(d_lab); run<3, 3>(d_lab);
+    run_pair<1, 4>(d_lab); run_pair<2, 4>(d_lab); run_pair<2, 5>(d_lab);
+    run_pair<2, 6>(d_lab); run_pair<2, 7>(d_lab); run_pair<2, 8>(d_lab); run_pair<1, 8>(d_lab);
     return 0;
 }

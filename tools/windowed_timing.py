@@ -27,3 +27,20 @@ for T, U, n in ((9500, 40, 30), (16000, 100, 29), (25000, 200, 29)):
     same = np.array_equal(res[0]["frame_of_label"], o["frame_of_label"])
     print(f"T={T} C={len(seg[1])}: GPU (host buffers, incl. alloc+copies) {gpu * 1e3:.0f} ms, oracle 1 core {cpu * 1e3:.0f} ms, "
           f"status {res[0]['status']}/{o['status']} frames equal: {same}", flush=True)
+
+# batch throughput: windowed segments in flight at once (one workgroup each; a 9 500-frame window is
+# bound by its sequential fp32 chain, so the chip only fills up across segments)
+T, U, n = 9500, 40, 30
+base = [pkg.synthetic.make_segment(20 + s, T, 32, U, n) for s in range(4)]
+cfg = pkg.CtcSegmentationParameters(index_duration=DUR)
+for B in (1, 32, 128, 256):
+    segs = [base[i % 4] for i in range(B)]
+    a, b, c = [s[0] for s in segs], [s[1] for s in segs], [s[2] for s in segs]
+    pkg.ctc_segmentation.get_segments_device(cfg, a, b, c, want_state=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = pkg.ctc_segmentation.get_segments_device(cfg, a, b, c, want_state=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"T={T} x {B} windowed segments in one call: {dt * 1e3:.0f} ms = {B / dt:.1f} segments/s = "
+          f"{B * T / dt:.3g} frames/s (host buffers, incl. copies)", flush=True)
