@@ -179,6 +179,41 @@ int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, in
                                float* char_prob, int32_t* state, double* seg_start, double* seg_end,
                                double* seg_score, int32_t* t_end, int32_t* status, void* stream);
 
+/*
+ * Segments that SHARE EMISSIONS, and one trellis fill where their texts are prefixes of one another.
+ * Replaces the repeat loop of the anchor iteration: after a low-scoring last utterance the reference
+ * calls get_segments again with the same `lpz` and the text minus its last utterance
+ * (src/iterative_utterance_alignment.py:201 once per window, :203 loop, :283,352,374 drop) -- a
+ * new table fill per attempt.  Here the attempts are segments of ONE call:
+ *   emission_of[b] = e <= b : segment b uses the emissions of segment e (emission_of[e] == e,
+ *                             T[e] == T[b]); `lpz` holds only the blocks of the segments with
+ *                             emission_of[b] == b, back to back, in segment order.
+ * Members of an emission group whose label sequence is a proper prefix of the group's longest aligned
+ * member are served by that member's fill (column c of the trellis depends on columns <= c only): one
+ * fill, one backtrack + scoring per member, results identical to separate calls.  Other members
+ * (different text, equal length, status != 0, vocab > 128, T > min_window_size, more than 15 prefixes,
+ * two prefixes ending in the same lane) are filled by themselves over the shared emissions.
+ * Inputs other than `lpz` and all outputs are laid out exactly as for ctcfa_align_batch (every
+ * segment has its own labels, utt_begin, frame_of_label, char_prob, ... regions).
+ * lpz_on_device != 0: `lpz` is a device pointer and `stream` the hipStream_t it was produced on
+ * (as ctcfa_align_batch_resident); else a host pointer (`stream` ignored).
+ */
+int ctcfa_align_batch_shared(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                             const int32_t* T, const int32_t* C, const int32_t* U, const int32_t* emission_of,
+                             const float* lpz, int32_t lpz_on_device, const int32_t* labels,
+                             const int32_t* utt_begin, int32_t* frame_of_label, float* char_prob, int32_t* state,
+                             double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
+                             int32_t* status, void* stream);
+
+/* Plan for the same geometry (ctcfa_plan_run_device / _pipelined then take `d_lpz` with the shared
+ * blocks once).  labels: HOST array of all segments' labels back to back, used to check the prefix
+ * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes. */
+int ctcfa_plan_create_shared(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
+                             int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
+                             const int32_t* emission_of, const int32_t* labels, int32_t force_cols_per_lane);
+/* how many trellis fills / emission blocks the plan's batch needs (either pointer may be NULL) */
+int ctcfa_plan_get_sharing(const ctcfa_plan* plan, int32_t* n_fills, int32_t* n_emission_blocks);
+
 #ifdef __cplusplus
 }
 #endif

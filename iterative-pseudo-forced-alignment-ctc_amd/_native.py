@@ -26,6 +26,7 @@ EXPORTS = (
     "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_run_pipelined", "ctcfa_plan_flush",
     "ctcfa_plan_get_timings",
     "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch", "ctcfa_align_batch_resident",
+    "ctcfa_align_batch_shared", "ctcfa_plan_create_shared", "ctcfa_plan_get_sharing",
 )
 
 
@@ -103,6 +104,11 @@ def load():
                                       i32p, i32p, i32p] + [vp] * 11
     lib.ctcfa_align_batch_resident.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
                                                i32p, i32p, i32p] + [vp] * 12
+    lib.ctcfa_align_batch_shared.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
+                                             i32p, i32p, i32p, i32p, vp, ctypes.c_int32] + [vp] * 11
+    lib.ctcfa_plan_create_shared.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(Params), ctypes.c_int32,
+                                             ctypes.c_int32, i32p, i32p, i32p, i32p, i32p, ctypes.c_int32]
+    lib.ctcfa_plan_get_sharing.argtypes = [vp, i32p, i32p]
     _lib = lib
     return lib
 
@@ -160,20 +166,31 @@ class Engine:
             raise exc(f"{what} failed ({rc}): {msg}")
 
     def align_batch(self, params, lpz_list, labels_list, utt_begin_list=None, want_state=True, d_lpz=None,
-                    stream=None, shapes=None):
+                    stream=None, shapes=None, emission_of=None):
         """Host-buffer entry ``ctcfa_align_batch``, or -- with ``d_lpz`` (device address of the
         concatenated fp32 emissions) and ``shapes`` = [(T_b, V), ...] -- ``ctcfa_align_batch_resident``.
 
         lpz_list: fp32 [T_b, V]; labels_list: int [C_b] (ground_truth_mat[:, 0]);
         utt_begin_list: int [U_b + 1] or None.  Returns a list of per-segment dicts.
+
+        emission_of (``ctcfa_align_batch_shared``): emission_of[b] = index of the segment whose
+        emissions segment b uses; only the blocks of segments with emission_of[b] == b are read from
+        ``lpz_list`` / expected at ``d_lpz`` (``shapes`` still lists every segment).
         """
         shapes = shapes or [l.shape for l in lpz_list]
         B = len(shapes)
         V = int(shapes[0][1])
         T = _i32([sh[0] for sh in shapes])
         C = _i32([len(g) for g in labels_list])
+        if emission_of is not None:
+            emission_of = _i32(emission_of)
+            if len(emission_of) != B:
+                raise ValueError("emission_of must have one entry per segment")
+            if all(int(e) == b for b, e in enumerate(emission_of)):
+                emission_of = None
         if d_lpz is None:
-            lpz = lpz_list[0].reshape(-1) if B == 1 else np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in lpz_list])
+            own = [l for b, l in enumerate(lpz_list) if emission_of is None or int(emission_of[b]) == b]
+            lpz = own[0].reshape(-1) if len(own) == 1 else np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in own])
             lpz = np.ascontiguousarray(lpz, dtype=np.float32)
         labels = _i32(labels_list[0]) if B == 1 else _i32(np.concatenate([np.asarray(g).reshape(-1) for g in labels_list]))
         have_utt = utt_begin_list is not None
@@ -190,7 +207,14 @@ class Engine:
         tail = (_ptr(labels), _ptr(ub), _ptr(fol), _ptr(cp), _ptr(state),
                 _ptr(seg[0]) if have_utt else None, _ptr(seg[1]) if have_utt else None,
                 _ptr(seg[2]) if have_utt else None, _ptr(t_end), _ptr(status))
-        if d_lpz is None:
+        if emission_of is not None:
+            rc = self._lib.ctcfa_align_batch_shared(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
+                                                    _i32p(emission_of),
+                                                    _ptr(lpz) if d_lpz is None else ctypes.c_void_p(int(d_lpz)),
+                                                    0 if d_lpz is None else 1, *tail,
+                                                    ctypes.c_void_p(stream) if stream else None)
+            self._check(rc, "ctcfa_align_batch_shared")
+        elif d_lpz is None:
             rc = self._lib.ctcfa_align_batch(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
                                              _ptr(lpz), *tail)
             self._check(rc, "ctcfa_align_batch")
@@ -215,22 +239,34 @@ class Engine:
             out.append(d)
         return out
 
-    def plan(self, params, vocab, T, C, U=None, force_cols_per_lane=0):
-        return Plan(self, params, vocab, T, C, U, force_cols_per_lane)
+    def plan(self, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None):
+        return Plan(self, params, vocab, T, C, U, force_cols_per_lane, emission_of, labels)
 
 
 class Plan:
     """Batch geometry + HBM workspace (``ctcfa_plan``); run it on device-resident buffers."""
 
-    def __init__(self, engine, params, vocab, T, C, U=None, force_cols_per_lane=0):
+    def __init__(self, engine, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None):
+        """emission_of / labels: ``ctcfa_plan_create_shared`` (segments that share emissions; ``labels`` =
+        all segments' labels back to back, for the prefix check, or None)."""
         self._eng = engine
         self._lib = engine._lib
         T, C = _i32(T), _i32(C)
         U = _i32(U) if U is not None else None
         h = ctypes.c_void_p()
-        rc = self._lib.ctcfa_plan_create(engine._h, ctypes.byref(h), ctypes.byref(params), len(T), int(vocab),
-                                         _i32p(T), _i32p(C), _i32p(U), int(force_cols_per_lane))
-        engine._check(rc, "ctcfa_plan_create")
+        if emission_of is None:
+            rc = self._lib.ctcfa_plan_create(engine._h, ctypes.byref(h), ctypes.byref(params), len(T), int(vocab),
+                                             _i32p(T), _i32p(C), _i32p(U), int(force_cols_per_lane))
+            engine._check(rc, "ctcfa_plan_create")
+        else:
+            emission_of = _i32(emission_of)
+            labels = _i32(labels) if labels is not None else None
+            if len(emission_of) != len(T) or (labels is not None and len(labels) != int(C.sum())):
+                raise ValueError("emission_of: one entry per segment; labels: sum(C) entries")
+            rc = self._lib.ctcfa_plan_create_shared(engine._h, ctypes.byref(h), ctypes.byref(params), len(T), int(vocab),
+                                                    _i32p(T), _i32p(C), _i32p(U), _i32p(emission_of), _i32p(labels),
+                                                    int(force_cols_per_lane))
+            engine._check(rc, "ctcfa_plan_create_shared")
         self._h = h
         self.T, self.C, self.U = T, C, U
         info = PlanInfo()
@@ -247,6 +283,12 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def sharing(self):
+        """-> (trellis fills, emission blocks) this batch needs."""
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        self._eng._check(self._lib.ctcfa_plan_get_sharing(self._h, ctypes.byref(a), ctypes.byref(b)), "ctcfa_plan_get_sharing")
+        return a.value, b.value
 
     def set_timing_stride(self, stride):
         """Record timing events only on every ``stride``-th run."""

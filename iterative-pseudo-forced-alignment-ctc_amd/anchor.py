@@ -280,11 +280,20 @@ def run_sequential(coroutine, aligner):
         return stop.value
 
 
-def run_batched(coroutines, aligner, batch_lpz=False, frames_fn=None):
+def run_batched(coroutines, aligner, batch_lpz=False, frames_fn=None, speculate=0, stats=None):
     """Advance many file coroutines in lockstep; all DP requests pending in a round go to the
     engine in one launch (``aligner.get_segments_batch``).  With ``batch_lpz`` the emission
     requests of a round also share one padded encoder forward (``aligner.get_lpz_batch``; see
-    its note on numerics).  Returns the result lists in order."""
+    its note on numerics).  Returns the result lists in order.
+
+    ``speculate`` = n > 0: every DP request also asks, in the same launch, for the n texts the
+    state machine may ask for next over the same emissions -- the window's text minus its last
+    1..n utterances (the repeats of ``iterative_utterance_alignment.py:203,283,352,374``).  They
+    share the request's emissions and, being prefixes of its text, its trellis fill
+    (``ctcfa_align_batch_shared``); a later request that was foreseen is answered from these results
+    without another launch and read-back.  The answers are the ones a launch would give: the same
+    ``prepare_segmentation_task`` / ``get_segments`` on the same arguments.
+    ``stats`` (dict, optional) counts rounds, DP launches, requests and requests answered ahead."""
     results = [None] * len(coroutines)
     pending = {}
     for i, co in enumerate(coroutines):
@@ -293,10 +302,24 @@ def run_batched(coroutines, aligner, batch_lpz=False, frames_fn=None):
         except StopIteration as stop:
             results[i] = stop.value
     batch_fn = getattr(aligner, "get_segments_batch", None)
+    if stats is None:
+        stats = {}
+    for k in ("rounds", "launches", "requests", "answered_ahead", "tasks"):
+        stats.setdefault(k, 0)
+    ahead = {}    # file -> (emissions object, name, n_samples, {tuple(utterances): answer})
+
+    def foreseen(i, r):
+        hit = ahead.get(i)
+        if hit is None or r[0] != "segments" or hit[0] is not r[2] or hit[1] != r[3] or hit[2] != r[4]:
+            return None
+        return hit[3].get(tuple(r[1]))
+
     while pending:
         answers = {}
         dp = [(i, r) for i, r in pending.items() if r[0] == "segments"]
         lz = [(i, r) for i, r in pending.items() if r[0] == "lpz"]
+        stats["rounds"] += 1
+        stats["requests"] += len(dp)
         if batch_lpz and len(lz) > 1 and hasattr(aligner, "get_lpz_batch"):
             for (i, _), lpz in zip(lz, aligner.get_lpz_batch([r[1] for _, r in lz], frames_fn=frames_fn)):
                 answers[i] = lpz
@@ -304,30 +327,60 @@ def run_batched(coroutines, aligner, batch_lpz=False, frames_fn=None):
             for i, r in lz:
                 answers[i] = aligner.get_lpz(r[1])
         if dp and batch_fn is not None:
-            tasks, owners = [], []
+            tasks, owners = [], []     # owners: (file, None) = the request itself, (file, key) = a foreseen text
             for i, r in dp:
                 try:
                     tasks.append(aligner.prepare_segmentation_task(r[1], r[2], r[3], r[4]))
-                    owners.append(i)
+                    owners.append((i, None))
                 except AssertionError as exc:
                     answers[i] = exc
-            for i, task, res in zip(owners, tasks, batch_fn(tasks)):
+                    continue
+                ahead[i] = (r[2], r[3], r[4], {})
+                for d in range(1, speculate + 1):
+                    if len(r[1]) - d < 1:
+                        break
+                    shorter = list(r[1][:len(r[1]) - d])
+                    try:
+                        tasks.append(aligner.prepare_segmentation_task(shorter, r[2], r[3], r[4]))
+                        owners.append((i, tuple(shorter)))
+                    except AssertionError:
+                        break          # (asked for in earnest later, it raises the same way then)
+            stats["launches"] += 1 if tasks else 0
+            stats["tasks"] += len(tasks)
+            for (i, key), task, res in zip(owners, tasks, batch_fn(tasks)):
                 if isinstance(res, Exception):
                     if not isinstance(res, AssertionError):
-                        raise res
-                    answers[i] = res
+                        if key is None:
+                            raise res
+                        continue       # a foreseen text the kernels cannot take: not answered ahead
+                    ans = res
                 else:
                     task.set(**res)
-                    answers[i] = parse_task_lines(str(task))
+                    ans = parse_task_lines(str(task))
+                if key is None:
+                    answers[i] = ans
+                else:
+                    ahead[i][3][key] = ans
         else:
             for i, r in dp:
                 answers[i] = _answer_segments(aligner, r)
         nxt = {}
         for i, ans in answers.items():
             try:
-                nxt[i] = coroutines[i].send(ans)
+                req = coroutines[i].send(ans)
+                while True:
+                    hit = foreseen(i, req)
+                    if hit is None:
+                        break
+                    stats["requests"] += 1
+                    stats["answered_ahead"] += 1
+                    req = coroutines[i].send(hit)
+                if req[0] != "segments":
+                    ahead.pop(i, None)
+                nxt[i] = req
             except StopIteration as stop:
                 results[i] = stop.value
+                ahead.pop(i, None)
         pending = nxt
     return results
 

@@ -72,7 +72,13 @@ struct ctcfa_plan {
     int ev_stride = 1;       // record timing events on every ev_stride-th run
     int64_t run_counter = 0;
     void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                    const ctcfa::FillRoles*) = nullptr;
+                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*) = nullptr;
+    // shared fills: watch columns of every group, the widest group, unique emission frames
+    std::vector<ctcfa::WatchDesc> watch;
+    ctcfa::WatchDesc* d_watch = nullptr;
+    int nwatch_max = 0;
+    int n_fill = 0;                   // segments that get a fill workgroup of their own
+    int64_t total_lpz_T = 0;
     // windowed regime (T > min_window_size): segment indices, fp32 table + per-column offsets
     std::vector<int32_t> win_list;
     int32_t* d_win_list = nullptr;
@@ -117,7 +123,7 @@ struct DeviceGuard {
     } while (0)
 
 using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                        const ctcfa::FillRoles*);
+                        const ctcfa::FillRoles*, const ctcfa::WatchDesc*);
 
 template <int VP, bool CK>
 FillFn fill_for_k(int K) {
@@ -211,10 +217,11 @@ int waves_of(int W, int nprod) {
     return W + nprod;
 }
 
-int lds_bytes_fill(int NS, int W, int K, int VP) {
+int lds_bytes_fill(int NS, int W, int K, int VP, int nwatch = 0) {
     // emission ring (NS slots) + exchange rings + last-column ring + counters + sink
+    // (+ shared fills: a ring and a target offset per watch column)
     return NS * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + W * ctcfa::kGroups * NS * ctcfa::halo_lanes(K) * K * 4 +
-           64 * 4 + ctcfa::kFlagInts * 4 + ctcfa::kSinkBytes;
+           64 * 4 + ctcfa::kFlagInts * 4 + ctcfa::kSinkBytes + nwatch * (64 * 4 + 8);
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
@@ -245,7 +252,7 @@ int vgprs_of(int K, bool ckpt) {  // compiled register counts, rounded up to the
 constexpr int kBacktrackVgprs = 96;   // backtrack_kernel<*>: __launch_bounds__(256, 5)
 
 bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_cu, int force_k, int nprod,
-                bool ckpt, ShapeChoice* out) {
+                bool ckpt, int nwatch, ShapeChoice* out) {
     double best_cost = -1.0;
     ShapeChoice best{0, 0, 0};
     const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
@@ -255,6 +262,7 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
     auto r512 = [](int v) { return (v + 511) / 512 * 512; };  // LDS is handed out in 512-byte units
     for (int K : kKs) {
         if (force_k && K != force_k) continue;
+        if (nwatch > 0 && K > ctcfa::kWatchMaxK) continue;   // shared fills: the watch variant of the row loop
         const int U = tile_useful_cols(K);
         const int W = (Cmax + (K - 1) + U - 1) / U;   // (the left padding can take up to K-1 columns)
         const int waves_per_wg = waves_of(W, nprod);
@@ -264,12 +272,12 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
         int NS = ns_forced ? ns_forced : 4;
         if (!ns_forced) {
             const int want = std::min(wg_per_cu_needed, 2);
-            if (want * r512(lds_bytes_fill(4, W, K, VP)) + 2 * r512(lds_beside) > lds_limit &&
-                want * r512(lds_bytes_fill(3, W, K, VP)) + 2 * r512(lds_beside) <= lds_limit)
+            if (want * r512(lds_bytes_fill(4, W, K, VP, nwatch)) + 2 * r512(lds_beside) > lds_limit &&
+                want * r512(lds_bytes_fill(3, W, K, VP, nwatch)) + 2 * r512(lds_beside) <= lds_limit)
                 NS = 3;
-            if (lds_bytes_fill(NS, W, K, VP) > lds_limit) NS = 3;
+            if (lds_bytes_fill(NS, W, K, VP, nwatch) > lds_limit) NS = 3;
         }
-        const int lds = lds_bytes_fill(NS, W, K, VP);
+        const int lds = lds_bytes_fill(NS, W, K, VP, nwatch);
         if (lds > lds_limit) continue;
         const int active = W + nprod;   // (padding waves leave at once)
         const int g_lds = std::max(lds_limit / r512(lds), 1);
@@ -377,7 +385,9 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
         plan->d_roles = nullptr;
         plan->d_bits[0] = nullptr;
         plan->d_lastcol[0] = nullptr;
+        plan->d_watch = nullptr;
     }
+    if (plan->d_watch) (void)hipFree(plan->d_watch);
     if (plan->d_segs) (void)hipFree(plan->d_segs);
     if (plan->d_roles) (void)hipFree(plan->d_roles);
     if (plan->d_win_list) (void)hipFree(plan->d_win_list);
@@ -416,9 +426,15 @@ hipError_t scratch_get(ctcfa_engine* eng, int slot, void** p, size_t bytes) {
 
 // use_scratch: the plan lives for one synchronous ctcfa_align_batch call; its device tables and
 // workspace come from the engine's grow-only scratch and the uploads go onto the engine's stream
+//
+// emission_of (NULL: every segment has emissions of its own): emission_of[b] = e <= b, the segment whose
+// emissions b uses (emission_of[e] == e, T[e] == T[b]).  Members of such a group whose label sequence is
+// a proper prefix of the group's longest (host `labels`, all segments back to back; NULL: the caller
+// vouches for it) share its trellis fill: SegDesc::watch_*.
 int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
                      int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
-                     int32_t force_k, bool use_scratch) {
+                     int32_t force_k, bool use_scratch, const int32_t* emission_of = nullptr,
+                     const int32_t* labels = nullptr) {
     if (!eng || !out || !params || !T || !C) return set_err(eng, CTCFA_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (batch <= 0 || vocab <= 0) return set_err(eng, CTCFA_ERR_INVALID, "batch and vocab must be positive");
@@ -453,6 +469,15 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             return set_err(eng, CTCFA_ERR_INVALID, "need T >= 1, C >= 2 ([-1, ..., blank]) and U >= 0");
         }
     }
+    if (emission_of)
+        for (int b = 0; b < batch; ++b) {
+            const int e = emission_of[b];
+            if (e < 0 || e > b || emission_of[e] != e || T[e] != T[b]) {
+                delete pl;
+                return set_err(eng, CTCFA_ERR_INVALID,
+                               "emission_of[b] must name an earlier segment (or b itself) that has emissions of its own and the same T");
+            }
+        }
     pl->gather = gather;
     // Vocabularies staged row by row (33..128 entries other than the vectorised pitch 64) take two
     // producer waves, each staging every other row: one alone cannot keep six tiles fed.
@@ -484,6 +509,44 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             Tmax = std::max(Tmax, (int)T[b]);
         }
     }
+    // Shared fills: per emission group, the longest aligned member leads; members whose labels are a
+    // proper prefix of its labels follow (everything else over the same emissions is filled by itself).
+    std::vector<int32_t> leader(batch);
+    for (int b = 0; b < batch; ++b) leader[b] = b;
+    int nwatch_bound = 0;
+    if (emission_of && !gather) {
+        std::vector<int64_t> lab_at(batch);
+        {
+            int64_t o = 0;
+            for (int b = 0; b < batch; ++b) {
+                lab_at[b] = o;
+                o += C[b];
+            }
+        }
+        std::vector<int32_t> lead_of_block(batch, -1);
+        for (int b = 0; b < batch; ++b) {   // longest aligned member of every emission block (first on ties)
+            if (pre[b] != CTCFA_ST_OK) continue;
+            int32_t& L = lead_of_block[emission_of[b]];
+            if (L < 0 || C[b] > C[L]) L = b;
+        }
+        std::vector<int32_t> members(batch, 0);
+        for (int b = 0; b < batch; ++b) {
+            if (pre[b] != CTCFA_ST_OK) continue;
+            const int L = lead_of_block[emission_of[b]];
+            if (L == b || C[b] >= C[L]) continue;
+            if (labels && std::memcmp(labels + lab_at[b], labels + lab_at[L], sizeof(int32_t) * (size_t)C[b]) != 0) continue;
+            if (members[L] + 2 > ctcfa::kMaxWatch) continue;   // (the leader's own column takes one entry)
+            leader[b] = L;
+            ++members[L];
+        }
+        for (int b = 0; b < batch; ++b)
+            if (members[b]) nwatch_bound = std::max(nwatch_bound, members[b] + 1);
+    }
+    auto n_fill_of = [&]() {
+        int n = 0;
+        for (int b = 0; b < batch; ++b) n += (pre[b] == CTCFA_ST_OK && leader[b] == b);
+        return std::max(n, 1);
+    };
     // Checkpoint mode (vocab <= 64): the fill stores the table row every 32-row block ends in instead
     // of decision words (3 instead of 9 VALU per cell) and the backtrack recomputes the decisions
     // along the path -- a longer, serial backtrack.  It pays where the fill is what a batch waits
@@ -493,8 +556,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         const bool can = !gather && pl->VP <= 64;
         // (the host-buffer entry runs fill and backtrack one after the other: there the longer
         // backtrack only pays once the fill is several times its length)
-        const bool pays = use_scratch ? (int64_t)batch * Cmax >= 1024 * 1024
-                                      : Cmax >= 544 || ((int64_t)batch * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
+        const int64_t nf = n_fill_of();
+        const bool pays = use_scratch ? nf * Cmax >= 1024 * 1024
+                                      : Cmax >= 544 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
     }
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
@@ -514,8 +578,15 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         pl->roles.nstages = W;
         pl->roles.cpad = 64 * W;
     } else {
-        if (!pick_shape(batch, Cmax, pl->VP, eng->lds_limit, bt_lds_estimate, eng->num_cu, force_k, nprod, pl->ckpt,
-                        &shape)) {
+        bool ok = pick_shape(n_fill_of(), Cmax, pl->VP, eng->lds_limit, bt_lds_estimate, eng->num_cu, force_k, nprod,
+                             pl->ckpt, nwatch_bound, &shape);
+        if (!ok && nwatch_bound > 0) {   // too many label columns for the tile widths that can watch: no sharing
+            for (int b = 0; b < batch; ++b) leader[b] = b;
+            nwatch_bound = 0;
+            ok = pick_shape(n_fill_of(), Cmax, pl->VP, eng->lds_limit, bt_lds_estimate, eng->num_cu, force_k, nprod,
+                            pl->ckpt, 0, &shape);
+        }
+        if (!ok) {
             delete pl;
             return set_err(eng, force_k ? CTCFA_ERR_INVALID : CTCFA_ERR_UNSUPPORTED,
                            force_k ? "cols_per_lane: not a compiled tile width, or too narrow for this batch"
@@ -534,15 +605,42 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     }
     const int K = pl->K;
     const int64_t Cpad = pl->roles.cpad;
-    pl->lds_fill = gather ? (pl->W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + ctcfa::kSinkBytes
-                          : lds_bytes_fill(shape.NS, pl->W, K, pl->VP);
     const int tileU = gather ? 64 : tile_useful_cols(K);
     const int tileHL = gather ? 0 : ctcfa::halo_lanes(K);
+    // Watch columns: one lane publishes one column.  A member whose last column shares a lane with
+    // another member's (utterances of one or two labels under wide tiles) is filled by itself.
+    std::vector<std::vector<int32_t>> followers(batch);
+    if (nwatch_bound > 0) {
+        auto lane_key = [&](int pcol) { return (pcol / tileU) * 64 + tileHL + (pcol % tileU) / K; };
+        std::vector<std::vector<int32_t>> taken(batch);
+        for (int b = 0; b < batch; ++b) {
+            const int L = leader[b];
+            if (L == b) continue;
+            const int shiftL = ((K - 1) - (C[L] - 1) % K + K) % K;
+            if (taken[L].empty()) taken[L].push_back(lane_key(C[L] - 1 + shiftL));
+            const int key = lane_key(C[b] - 1 + shiftL);
+            if (std::find(taken[L].begin(), taken[L].end(), key) != taken[L].end()) {
+                leader[b] = b;
+                continue;
+            }
+            taken[L].push_back(key);
+            followers[L].push_back(b);
+        }
+        nwatch_bound = 0;
+        for (int b = 0; b < batch; ++b)
+            if (!followers[b].empty()) nwatch_bound = std::max(nwatch_bound, (int)followers[b].size() + 1);
+    }
+    pl->nwatch_max = nwatch_bound;
+    pl->roles.reserved[0] = nwatch_bound;
+    pl->lds_fill = gather ? (pl->W + 1) * ctcfa::kBndPitch * 4 + 64 * 4 + ctcfa::kSinkBytes
+                          : lds_bytes_fill(shape.NS, pl->W, K, pl->VP, nwatch_bound);
+    pl->n_fill = n_fill_of();
     pl->segs.resize(batch);
     int64_t lpz_off = 0, lab_off = 0, frm_off = 0, utt_off = 0, bits_off = 0;
     for (int b = 0; b < batch; ++b) {
         SegDesc& s = pl->segs[b];
-        s.lpz_off = lpz_off;
+        const bool own_emissions = !emission_of || emission_of[b] == b;
+        s.lpz_off = own_emissions ? lpz_off : pl->segs[emission_of[b]].lpz_off;
         s.lab_off = lab_off;
         s.frm_off = frm_off;
         s.utt_off = utt_off;
@@ -583,13 +681,34 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         }
         const int nblk = (T[b] - 1 + ctcfa::kRows - 1) / ctcfa::kRows;
         pl->nblk_max = std::max(pl->nblk_max, nblk);
-        lpz_off += (int64_t)T[b] * vocab;
+        if (own_emissions) {
+            lpz_off += (int64_t)T[b] * vocab;
+            pl->total_lpz_T += T[b];
+        }
         lab_off += C[b];
         frm_off += T[b];
         utt_off += s.U;
-        if (s.prestatus == CTCFA_ST_OK) bits_off += (int64_t)nblk * Cpad;
-        // 4TV + TC/8 + 4T + 8C + 4T
-        pl->alg_bytes += 4LL * T[b] * vocab + (int64_t)T[b] * C[b] / 8 + 4LL * T[b] + 8LL * C[b] + 4LL * T[b];
+        const bool own_fill = s.prestatus == CTCFA_ST_OK && leader[b] == b;
+        if (own_fill) bits_off += (int64_t)nblk * Cpad;
+        // 4TV + TC/8 + 4T + 8C + 4T (emissions and trace words once per shared fill)
+        pl->alg_bytes += (own_emissions ? 4LL * T[b] * vocab : 0) + (own_fill ? (int64_t)T[b] * C[b] / 8 : 0) +
+                         4LL * T[b] + 8LL * C[b] + 4LL * T[b];
+    }
+    for (int b = 0; b < batch; ++b) {   // followers walk their leader's trace; leaders list the watch columns
+        SegDesc& s = pl->segs[b];
+        if (leader[b] != b) {
+            const SegDesc& l = pl->segs[leader[b]];
+            s.bits_off = l.bits_off;
+            s.shift = l.shift;
+            s.fill_skip = 1;
+        } else if (!followers[b].empty()) {
+            s.watch_first = (int32_t)pl->watch.size();
+            s.watch_n = (int32_t)followers[b].size() + 1;
+            std::vector<int32_t> m = followers[b];
+            m.push_back(b);
+            std::sort(m.begin(), m.end(), [&](int x, int y) { return C[x] < C[y]; });
+            for (int x : m) pl->watch.push_back(ctcfa::WatchDesc{pl->segs[x].frm_off, C[x] - 1 + s.shift, 0});
+        }
     }
     pl->total_T = frm_off;
     pl->total_C = lab_off;
@@ -639,6 +758,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
         PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
         PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+        if (!pl->watch.empty()) {
+            PLAN_TRY(hipMalloc(&pl->d_watch, sizeof(ctcfa::WatchDesc) * pl->watch.size()));
+            PLAN_TRY(hipMemcpy(pl->d_watch, pl->watch.data(), sizeof(ctcfa::WatchDesc) * pl->watch.size(), hipMemcpyHostToDevice));
+        }
     }
     if (pl->lds_fill > 48 * 1024 && pl->fill_fn)
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
@@ -748,7 +871,7 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
     hipExtLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, start, stop, 0,
                           pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
                           (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0,
-                          (const ctcfa::FillRoles*)pl->d_roles);
+                          (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }
@@ -923,16 +1046,17 @@ hipError_t pinned_get(unsigned char** p, size_t* cap, size_t bytes) {
 // kernels, ONE result download.  An anchor iteration issues hundreds of such calls for windows of a
 // few hundred frames: what a call costs beyond its kernels is what this function keeps small.
 int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab, const int32_t* T,
-               const int32_t* C, const int32_t* U, const float* host_lpz, const float* dev_lpz, hipStream_t st,
+               const int32_t* C, const int32_t* U, const int32_t* emission_of, const float* host_lpz,
+               const float* dev_lpz, hipStream_t st,
                const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label, float* char_prob,
                int32_t* state, double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
                int32_t* status) {
     DeviceGuard on_device(eng->device);
     ctcfa_plan* pl = nullptr;
-    int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true);
+    int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of, labels);
     if (rc != CTCFA_OK) return rc;
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
-    const size_t n_lpz = (size_t)pl->total_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
+    const size_t n_lpz = (size_t)pl->total_lpz_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
     const size_t n_utt = (size_t)pl->total_U, n_ub = n_utt + batch;
     auto cleanup = [&]() {  // the buffers are the engine's scratch; quiesce before the next call reuses them
         (void)hipStreamSynchronize(st);
@@ -948,9 +1072,11 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
         }                                                                                 \
     } while (0)
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    // packed upload: role table | segment table | labels | utterance starts
+    // packed upload: role table | segment table | labels | utterance starts | watch columns of shared fills
+    const size_t n_watch = pl->watch.size();
     const size_t in_roles = 0, in_segs = up(sizeof(ctcfa::FillRoles)), in_lab = in_segs + up(sizeof(SegDesc) * (size_t)batch),
-                 in_ub = in_lab + up(n_lab * 4), in_bytes = in_ub + (want_seg ? up(n_ub * 4) : 0);
+                 in_ub = in_lab + up(n_lab * 4), in_watch = in_ub + (want_seg ? up(n_ub * 4) : 0),
+                 in_bytes = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc));
     const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
                  o_tend = o_state + (state ? up(n_frm * 4) : 0), o_status = o_tend + up((size_t)batch * 4),
                  o_seg = o_status + up((size_t)batch * 4), out_bytes = o_seg + (want_seg ? up(3 * n_utt * 8) : 0);
@@ -966,10 +1092,12 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     std::memcpy(h + in_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch);
     std::memcpy(h + in_lab, labels, n_lab * 4);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
+    if (n_watch) std::memcpy(h + in_watch, pl->watch.data(), n_watch * sizeof(ctcfa::WatchDesc));
     AB_TRY(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, st));
     if (host_lpz) AB_TRY(hipMemcpyAsync(d_lpz, host_lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
     pl->d_roles = reinterpret_cast<ctcfa::FillRoles*>(d_in + in_roles);
     pl->d_segs = reinterpret_cast<SegDesc*>(d_in + in_segs);
+    pl->d_watch = n_watch ? reinterpret_cast<ctcfa::WatchDesc*>(d_in + in_watch) : nullptr;
     int32_t* d_lab = reinterpret_cast<int32_t*>(d_in + in_lab);
     int32_t* d_ub = want_seg ? reinterpret_cast<int32_t*>(d_in + in_ub) : nullptr;
     double* d_seg = want_seg ? reinterpret_cast<double*>(d_out + o_seg) : nullptr;
@@ -1010,8 +1138,8 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
     if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
-    return align_impl(eng, params, batch, vocab, T, C, U, lpz, nullptr, eng->stream, labels, utt_begin, frame_of_label,
-                      char_prob, state, seg_start, seg_end, seg_score, t_end, status);
+    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, lpz, nullptr, eng->stream, labels, utt_begin,
+                      frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
 }
 
 int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
@@ -1022,8 +1150,48 @@ int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, in
     if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
     if (!d_lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL buffer");
-    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, d_lpz, reinterpret_cast<hipStream_t>(stream), labels,
-                      utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
+    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, nullptr, d_lpz, reinterpret_cast<hipStream_t>(stream),
+                      labels, utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
+}
+
+int ctcfa_align_batch_shared(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                             const int32_t* T, const int32_t* C, const int32_t* U, const int32_t* emission_of,
+                             const float* lpz, int32_t lpz_on_device, const int32_t* labels,
+                             const int32_t* utt_begin, int32_t* frame_of_label, float* char_prob, int32_t* state,
+                             double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
+                             int32_t* status, void* stream) {
+    if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
+    if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status || !emission_of)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL buffer");
+    return align_impl(eng, params, batch, vocab, T, C, U, emission_of, lpz_on_device ? nullptr : lpz,
+                      lpz_on_device ? lpz : nullptr, lpz_on_device ? reinterpret_cast<hipStream_t>(stream) : eng->stream,
+                      labels, utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
+}
+
+int ctcfa_plan_create_shared(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
+                             int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
+                             const int32_t* emission_of, const int32_t* labels, int32_t force_k) {
+    return plan_create_impl(eng, out, params, batch, vocab, T, C, U, force_k, false, emission_of, labels);
+}
+
+int ctcfa_plan_get_sharing(const ctcfa_plan* pl, int32_t* n_fills, int32_t* n_emission_blocks) {
+    if (!pl) return CTCFA_ERR_INVALID;
+    if (n_fills) {
+        int n = 0;
+        for (const SegDesc& s : pl->segs) n += (s.prestatus == CTCFA_ST_OK && !s.fill_skip);
+        *n_fills = n;
+    }
+    if (n_emission_blocks) {
+        int n = 0;
+        int64_t last = -1;
+        for (const SegDesc& s : pl->segs)
+            if (s.lpz_off > last || last < 0) {
+                ++n;
+                last = s.lpz_off;
+            }
+        *n_emission_blocks = n;
+    }
+    return CTCFA_OK;
 }
 
 }  // extern "C"

@@ -79,7 +79,23 @@ struct SegDesc {
     int32_t owner_lane;   // ... and the lane inside it (the column sits at k == K-1 there)
     int64_t win_off;      // windowed segments: floats into the table workspace
     int64_t wcol_off;     // windowed segments: ints into the per-column offsets workspace
+    // Shared fills (ctcfa_*_shared): segments over the same emissions whose label sequences are prefixes
+    // of the group's longest one.  The longest (the LEADER) is filled; every member's last label column
+    // is a WATCH column of that fill (its scores go to lastcol + the member's frm_off), and the members'
+    // backtracks walk the leader's trace words (same bits_off, same shift).
+    int32_t watch_first;  // leader: first entry of this group in the watch table
+    int32_t watch_n;      // leader: entries (0: not a group -- only column C-1, by owner_stage / owner_lane)
+    int32_t fill_skip;    // follower: no fill workgroup of its own
+    int32_t reserved0;
 };
+
+struct WatchDesc {     // one watched label column of a shared fill, ascending pcol within a group
+    int64_t frm_off;   // where its scores go: lastcol + frm_off + t
+    int32_t pcol;      // padded column (label column + the leader's shift)
+    int32_t reserved;
+};
+constexpr int kMaxWatch = 16;        // watch columns per shared fill (more members: fills of their own)
+constexpr int kWatchMaxK = 2;        // widest tile the watch variant of the row loop is compiled for (wider ones are at their VGPR cap)
 
 // Launch shape of the fill kernel: what each wave of a workgroup does.  Tiles are numbered left
 // to right; a tile is one wave, lane l owns K consecutive padded columns.  The first HL lanes of a
@@ -172,7 +188,7 @@ __launch_bounds__((K >= 10) ? 320 : (K >= 8) ? 512 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int preamble,
-            const FillRoles* __restrict__ roles) {
+            const FillRoles* __restrict__ roles, const WatchDesc* __restrict__ watch) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int PITCH = VP + kPitchPad;  // row pitch in (e, m) entries; entry VP = start-column pseudo label
     constexpr int SLOT_BYTES = kRows * PITCH * 8;
@@ -189,21 +205,27 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const int w = my.stage;               // this wave's tile (compute waves)
 
     const SegDesc sd = segs[blockIdx.x];
-    if (sd.prestatus != 0) return;  // uniform: nothing to fill
+    if (sd.prestatus != 0 || sd.fill_skip) return;  // uniform: nothing to fill (or filled by its group's leader)
     const int T = sd.T, C = sd.C, shift = sd.shift;
     const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
+    const int wn = (K <= kWatchMaxK) ? sd.watch_n : 0;   // watch columns of a shared fill
+    const WatchDesc* __restrict__ seg_watch = watch + sd.watch_first;
 
     // LDS after the emission ring:
     //   xch    [W][XR][XW] floats  exchange rows: tile w's last XW columns at the end of group g in [w][g % XR]
     //   lcring [64] floats         last label column (owner tile), index t % 64
     //   flags  [32] ints           done[0..15], staged[16..17], posflag [18]
     //   sink   1 KB                target of the owner tile's lanes that publish nothing
+    //   wring  [nw][64] floats     shared fills: one ring like lcring per watch column
+    //   wtab   [nw] int64          ... and where its scores go in `lastcol`
     const uint32_t xch_base = static_cast<uint32_t>(NS * SLOT_BYTES);
     const uint32_t lcring_base = xch_base + static_cast<uint32_t>(W * XR * XW * 4);
     const uint32_t flag_base = lcring_base + 64 * 4;
     const uint32_t sink_base = flag_base + kFlagInts * 4;
+    const uint32_t wring_base = sink_base + kSinkBytes;
+    const uint32_t wtab_base = wring_base + static_cast<uint32_t>(roles->reserved[0] * 64 * 4);   // reserved[0]: watch columns of the widest group
     // (an explicit LDS pointer: a volatile access through a generic pointer compiles to flat_load +
     // s_waitcnt vmcnt(0), which would make the tiles wait for their own trace stores)
     lds_vint* flags = (lds_vint*)(smem + flag_base);
@@ -217,6 +239,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         float* xch = reinterpret_cast<float*>(smem + xch_base);
         for (int i = tid; i < W * XR * XW; i += blockDim.x) xch[i] = kProbMax;
         if (tid < kFlagInts) flags[tid] = (tid == 17 && roles->nprod < 2) ? kBigCount : 0;
+        if (tid < wn) reinterpret_cast<int64_t*>(smem + wtab_base)[tid] = seg_watch[tid].frm_off;
     }
     lds_barrier();  // the only workgroup barrier: everything after it is counter-paced
     if (my.role == kRoleIdle) return;
@@ -547,6 +570,25 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const int wstar = sd.owner_stage;  // tile that owns the last label column (ragged batches: <= W-1)
     const int lstar = sd.owner_lane;
     float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);  // .x = row 0 of every label column
+    // Shared fill: the watch columns this tile owns (halo lanes hold copies, not columns) are slots
+    // [ws_lo, ws_hi) of the group's list; the lane that holds slot `myslot` has it at k == ksel.
+    int ws_lo = 0, ws_hi = 0, myslot = -1, ksel = K - 1;
+    int next_watch = 0x7fffffff;   // smallest watch column at or right of this tile's first own column
+    if constexpr (K <= kWatchMaxK) {
+        for (int s = 0; s < wn; ++s) {
+            const int rel = seg_watch[s].pcol - cbase;
+            if (rel < HL * K) continue;
+            if (next_watch == 0x7fffffff) next_watch = seg_watch[s].pcol;
+            if (rel >= 64 * K) break;
+            if (ws_hi == 0) ws_lo = s;
+            ws_hi = s + 1;
+            if (lane == rel / K) {
+                myslot = s;
+                ksel = rel % K;
+            }
+        }
+    }
+    const bool watch_tile = ws_hi > ws_lo;
     // exchange rows: what I read (left neighbour's ring; lanes past the halo re-read its last entry) and
     // what I publish (my last HL lanes)
     const uint32_t xin_addr = xch_base + static_cast<uint32_t>(((w > 0 ? w - 1 : 0) * XR * XW + (lane < HL ? lane : HL - 1) * K) * 4);
@@ -585,8 +627,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     int jlast = nblk - 1;
     {
         const int cmax = (cbase + 64 * K - 1) - shift;     // right-most column of this tile
-        if (cmax < C - 1) {
-            const int tdead = T - C + cmax;                // last row where cmax is alive
+        // Shared fill: a column serves every member whose last column lies at or right of it; the
+        // shortest of them keeps it alive longest (and a watch column is needed in every row).
+        const int cend = (wn > 0 && next_watch != 0x7fffffff) ? next_watch - shift : C - 1;
+        if (cmax < cend) {
+            const int tdead = T - (cend + 1) + cmax;       // last row where cmax is alive
             jlast = tdead >= 1 ? (tdead - 1) / kRows : -1;
             if (jlast > nblk - 1) jlast = nblk - 1;
         }
@@ -625,16 +670,29 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #endif
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
 
-    // one 32-row block; OWNER: this tile holds the last label column and also publishes its scores
+    // scores of the watch columns of this tile, rows 32j .. 32j+31 (from the rings, or -1e9 for a
+    // block the tile skipped), to where the members' backtracks look for them
+    auto watch_out = [&](int j, bool from_ring) {
+        const int t = j * kRows + (lane & 31);
+        for (int s = ws_lo + (lane >> 5); s < ws_hi; s += 2) {
+            const int64_t off = *reinterpret_cast<const int64_t*>(smem + wtab_base + s * 8);
+            const float v = from_ring ? *reinterpret_cast<const float*>(smem + wring_base + (s * 64 + (j & 1) * kRows + (lane & 31)) * 4)
+                                      : kProbMax;
+            if (t >= 1 && t < T) lastcol[off + t] = v;
+        }
+    };
+    // one 32-row block; OWNER 1: this tile holds the last label column and also publishes its scores;
+    // OWNER 2 (shared fill): it holds watch columns, each in some lane at some k
     auto block = [&](int j, auto owner_tag) {
-        constexpr bool OWNER = decltype(owner_tag)::value;
+        constexpr int OWNER = decltype(owner_tag)::value;
         const int slot = j % NS;
         const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
         cur_slot = slot;
 #pragma unroll
         for (int k = 0; k < K; ++k) gaddr[k] += delta;
         uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 16);
-        if (OWNER && lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
+        if (OWNER == 1 && lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
+        if (OWNER == 2 && myslot >= 0) out_addr = wring_base + static_cast<uint32_t>((myslot * 64 + (j & 1) * kRows) * 4);
 
         // software pipeline: operands of row i+PF are requested while row i is computed
         constexpr int PF = CTCFA_PF;
@@ -678,12 +736,17 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
                 prev[k] = nw;
             }
-            if constexpr (OWNER) {
-                if ((i + 1) % 4 == 0) pub4.x = prev[K - 1];
-                else if ((i + 1) % 4 == 1) pub4.y = prev[K - 1];
-                else if ((i + 1) % 4 == 2) pub4.z = prev[K - 1];
+            if constexpr (OWNER != 0) {
+                float pv = prev[K - 1];
+                if constexpr (OWNER == 2) {
+#pragma unroll
+                    for (int k = 0; k < K - 1; ++k) pv = (ksel == k) ? prev[k] : pv;
+                }
+                if ((i + 1) % 4 == 0) pub4.x = pv;
+                else if ((i + 1) % 4 == 1) pub4.y = pv;
+                else if ((i + 1) % 4 == 2) pub4.z = pv;
                 else {
-                    pub4.w = prev[K - 1];
+                    pub4.w = pv;
                     *reinterpret_cast<float4*>(smem + out_addr + (i - 2) * 4) = pub4;
                 }
             }
@@ -756,11 +819,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #pragma unroll
             for (int k = 0; k < K; ++k) bp[k] = CK ? __float_as_uint(prev[k]) : dec[k];
         }
-        if constexpr (OWNER) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
+        if constexpr (OWNER == 1) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
             const int t = j * kRows + lane;
             if (lane < kRows && t >= 1 && t < T)
                 seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
         }
+        if constexpr (OWNER == 2) watch_out(j, true);
     };
 
     for (int j = 0; j <= jlast; ++j) {
@@ -784,7 +848,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         asm volatile("" ::: "memory");
         if (j < jfirst) {
             if (__builtin_amdgcn_readfirstlane(*posflag) == 0) {   // still provably -1e9 everywhere in this block
-                if (w == wstar) {
+                if (wn > 0) {
+                    watch_out(j, false);
+                } else if (w == wstar) {
                     const int t = j * kRows + lane;
                     if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
                 }
@@ -800,8 +866,14 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             }
             jfirst = 0;            // emissions are not log-probabilities: compute everything from here on
         }
-        if (w == wstar) block(j, std::true_type{});
-        else block(j, std::false_type{});
+        if constexpr (K <= kWatchMaxK) {
+            if (watch_tile) {
+                block(j, std::integral_constant<int, 2>{});
+                continue;
+            }
+        }
+        if (w == wstar && wn == 0) block(j, std::integral_constant<int, 1>{});
+        else block(j, std::integral_constant<int, 0>{});
     }
     if (lane == 63) flags[w] = kBigCount;   // done (end of the segment or dead zone): nobody waits for this tile again
 #ifdef CTCFA_STAMP
@@ -813,7 +885,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     return;
 #endif
     // row 32*nblk (present when (T-1) % 32 == 0) is still in pub4.x
-    if (w == wstar && lane == lstar && nblk * kRows < T) seg_lastcol[nblk * kRows] = pub4.x;
+    if (wn > 0) {
+        if (myslot >= 0 && nblk * kRows < T)
+            lastcol[*reinterpret_cast<const int64_t*>(smem + wtab_base + myslot * 8) + nblk * kRows] = pub4.x;
+    } else if (w == wstar && lane == lstar && nblk * kRows < T) {
+        seg_lastcol[nblk * kRows] = pub4.x;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

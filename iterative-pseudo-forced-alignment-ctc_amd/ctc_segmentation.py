@@ -234,13 +234,32 @@ def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, eng
     engine = engine or default_engine()
     labels = [_labels_from_mat(g) for g in ground_truth_list]
     _validate_segments(lpz_list, labels, utt_begin_list)
+    emission_of = shared_emissions(lpz_list)
     if lpz_list and all(_is_device_tensor(l) for l in lpz_list):
-        return _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state)
-    lpz_list = [np.ascontiguousarray(l.cpu().numpy() if hasattr(l, "cpu") else l, dtype=np.float32) for l in lpz_list]
-    return engine.align_batch(config.to_native(), lpz_list, labels, utt_begin_list, want_state=want_state)
+        return _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state, emission_of)
+    own = {}
+    for b, l in enumerate(lpz_list):   # (one conversion per emission block, not per segment)
+        e = b if emission_of is None else emission_of[b]
+        if e not in own:
+            own[e] = np.ascontiguousarray(l.cpu().numpy() if hasattr(l, "cpu") else l, dtype=np.float32)
+    lpz_list = [own[b if emission_of is None else emission_of[b]] for b in range(len(lpz_list))]
+    return engine.align_batch(config.to_native(), lpz_list, labels, utt_begin_list, want_state=want_state,
+                              emission_of=emission_of)
 
 
-def _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state):
+def shared_emissions(lpz_list):
+    """``emission_of`` for ``ctcfa_align_batch_shared``: entries of ``lpz_list`` that are THE SAME OBJECT
+    (the anchor loop's repeats: one ``lpz`` per window, the text shrinking by its last utterance,
+    ``iterative_utterance_alignment.py:201-219``) share their emissions -- and, where one text is a
+    prefix of the other, the trellis fill.  None when nothing is shared."""
+    first = {}
+    out = []
+    for b, l in enumerate(lpz_list):
+        out.append(first.setdefault(id(l), b))
+    return out if any(e != b for b, e in enumerate(out)) else None
+
+
+def _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state, emission_of=None):
     """Device-resident emissions (torch CUDA tensors): ``ctcfa_align_batch_resident`` on the current
     torch stream -- the emissions are used where they are, the small inputs go up in one packed copy,
     the results come back in one; no per-call device allocation."""
@@ -249,10 +268,11 @@ def _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state
     dev = lpz_list[0].device
     shapes = [(int(l.shape[0]), int(l.shape[1])) for l in lpz_list]
     flat = [l.reshape(-1) if l.dtype == torch.float32 and l.is_contiguous() else l.to(torch.float32).contiguous().reshape(-1)
-            for l in lpz_list]
+            for b, l in enumerate(lpz_list) if emission_of is None or emission_of[b] == b]
     d_lpz = flat[0] if len(flat) == 1 else torch.cat(flat)   # (one window: no copy at all)
     return engine.align_batch(config.to_native(), None, labels, utt_begin_list, want_state=want_state,
-                              d_lpz=d_lpz.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream, shapes=shapes)
+                              d_lpz=d_lpz.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream, shapes=shapes,
+                              emission_of=emission_of)
 
 
 def ctc_segmentation(config, lpz, ground_truth, engine=None):
