@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="synthetic", choices=["synthetic", "replay", "words", "corpus"])
     ap.add_argument("--files", type=int, default=64, help="replay: audio files advanced in lockstep per GPU")
+    ap.add_argument("--speculate", type=int, default=0,
+                    help="replay: every DP request also carries the n texts the repeat loop may ask for next (the window "
+                         "minus its last 1..n utterances) -- shared emissions and trellis fill, foreseen requests cost no round")
     ap.add_argument("--rows", type=int, default=10000, help="words: TSV rows of the whole job")
     ap.add_argument("--hours", type=float, default=100.0, help="corpus: audio hours of the whole job")
     ap.add_argument("--per-launch", type=int, default=0, help="words / corpus: segments per launch (0 = 2500 / 2048)")
@@ -124,15 +127,46 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
     V = args.vocab
     calls = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_windows.json")))["calls"]
     sequential = False
+    shared = None          # per group: emission_of (replay with --speculate)
+    frames_override = None
     if args.workload == "replay":
         # every round = one DP call of the recorded sequence for `files` files in lockstep (weak scaling:
         # `files` per GPU); the next round needs this round's scores on the host (anchor state machine)
-        base = syn.make_windows_like(calls, V, seed=rank)
-        groups = [[b] * args.files for b in base if len(b[1]) <= b[0].shape[0]]
+        ok_calls = [c for c in calls if c["C"] <= c["T"]]
         sequential, scaling = True, "weak"
-        name = ("BASELINE.json configs[1]: replay of the reference's sample file (519 s, 157 rows -> %d DP calls, "
-                "T %d..%d), %d files in lockstep per GPU, DP-only on synthetic emissions"
-                % (len(groups), min(c["T"] for c in calls), max(c["T"] for c in calls), args.files))
+        if args.speculate <= 0:
+            base = syn.make_windows_like(ok_calls, V, seed=rank)
+            groups = [[b] * args.files for b in base]
+            name = ("BASELINE.json configs[1]: replay of the reference's sample file (519 s, 157 rows -> %d DP calls, "
+                    "T %d..%d), %d files in lockstep per GPU, DP-only on synthetic emissions"
+                    % (len(groups), min(c["T"] for c in calls), max(c["T"] for c in calls), args.files))
+        else:
+            # windows = runs of calls over the same emissions, each the previous text minus its last utterance
+            # (iterative_utterance_alignment.py:203 loop).  A request carries `speculate` foreseen texts; a
+            # window of L calls then takes ceil(L / (speculate + 1)) rounds.  Foreseen texts are computed
+            # whether or not the state machine will ask for them -- the driver cannot know.
+            chains = []
+            for c in ok_calls:
+                if chains and chains[-1][-1]["T"] == c["T"] and chains[-1][-1]["utts"][:-1] == c["utts"]:
+                    chains[-1].append(c)
+                else:
+                    chains.append([c])
+            heads = []
+            for ch in chains:
+                heads += [ch[k] for k in range(0, len(ch), args.speculate + 1)]
+            base = syn.make_windows_like(heads, V, seed=rank)
+            groups, shared = [], []
+            for lpz, gt, ub in base:
+                U = len(ub) - 1
+                members = [(lpz, gt[:ub[k] + 1].copy(), ub[:k + 1].copy())
+                           for k in range(U, max(U - args.speculate, 0) - 1, -1) if k >= 1]
+                groups.append(members * args.files)
+                shared.append([f * len(members) for f in range(args.files) for _ in members])
+            frames_override = sum(c["T"] for c in ok_calls) * args.files   # the recorded calls: every one is answered
+            name = ("BASELINE.json configs[1]: replay of the reference's sample file (519 s, 157 rows -> %d DP calls in "
+                    "%d windows), %d files in lockstep per GPU, every request with %d foreseen text(s) over the same "
+                    "emissions and fill: %d rounds; frames counted = the recorded calls'; DP-only on synthetic emissions"
+                    % (len(ok_calls), len(chains), args.files, args.speculate, len(groups)))
     elif args.workload == "words":
         rows = syn.make_word_rows(args.rows, V)
         costs = [s[0].shape[0] * len(s[1]) for s in rows]
@@ -160,15 +194,16 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
     eng = pkg._native.Engine(local_rank)
     stream = torch.cuda.current_stream()
     G = []
-    for g in groups:
+    n_fills = 0
+    for gi, g in enumerate(groups):
         Ts = [s[0].shape[0] for s in g]
         Cs = [len(s[1]) for s in g]
         Us = [len(s[2]) - 1 for s in g]
-        plan = eng.plan(cfg.to_native(), V, Ts, Cs, Us, force_cols_per_lane=args.cols_per_lane)
-        uniq = {}
-        for s in g:                      # (replay tiles one window: upload it once per copy all the same)
-            uniq.setdefault(id(s), s)
-        d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in g])).to(dev)
+        em = shared[gi] if shared else None
+        plan = eng.plan(cfg.to_native(), V, Ts, Cs, Us, force_cols_per_lane=args.cols_per_lane, emission_of=em,
+                        labels=np.concatenate([s[1] for s in g]).astype(np.int32) if em else None)
+        n_fills += plan.sharing()[0]
+        d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for b, s in enumerate(g) if not em or em[b] == b])).to(dev)
         d_lab = torch.from_numpy(np.concatenate([s[1] for s in g]).astype(np.int32)).to(dev)
         d_ub = torch.from_numpy(np.concatenate([s[2] for s in g]).astype(np.int32)).to(dev)
         nT, nC, nU, B = sum(Ts), sum(Cs), max(1, sum(Us)), len(g)
@@ -177,7 +212,7 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
                      status=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(3)]
         G.append(dict(plan=plan, lpz=d_lpz, lab=d_lab, ub=d_ub, outs=outs, frames=nT, segs=g, n=0,
                       host=torch.empty(3, nU, dtype=torch.float64).pin_memory() if sequential else None))
-    frames_step = sum(g["frames"] for g in G)
+    frames_step = frames_override if frames_override is not None else sum(g["frames"] for g in G)
     pipelined = not args.serial and not sequential
 
     def run_group(g):
@@ -267,7 +302,8 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
 
     if rank == 0:
         fps = frames_all * args.steps / dt
-        fill_bytes = sum(4 * s[0].shape[0] * V + s[0].shape[0] * len(s[1]) // 8 for g in G for s in g["segs"])
+        fill_bytes = sum(4 * s[0].shape[0] * V + s[0].shape[0] * len(s[1]) // 8
+                         for gi, g in enumerate(G) for b, s in enumerate(g["segs"]) if not shared or shared[gi][b] == b)
         step_bytes = sum(g["plan"].info["algorithmic_bytes"] for g in G)
         shapes = sorted({(g["plan"].info["cols_per_lane"], g["plan"].info["waves_per_seg"]) for g in G})
         out = {
@@ -278,6 +314,7 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "launches_per_step": len(G), "segments_per_step_this_gpu": sum(len(g["segs"]) for g in G),
+                       "fills_per_step_this_gpu": n_fills,
                        "frames_per_step_this_gpu": frames_step, "vocab": V, "tile_shapes_K_W": shapes,
                        "parallelism": f"unit-sharded x{world}", "parity": parity,
                        "schedule": ("one launch at a time + host read-back of the scores after every round (the anchor "

@@ -97,7 +97,7 @@ def _write_tsv_atomic(path, rows, columns):
 
 
 def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params, opener=WavFile,
-                          rank=0, world=1, files_per_round=8):
+                          rank=0, world=1, files_per_round=8, speculate=1):
     """File loop of iterative_utterance_alignment.main (:436-475), ``files_per_round`` files in
     lockstep.  Returns the list of result TSV paths written by this rank.
 
@@ -105,7 +105,8 @@ def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params
     no claim file is needed; a file whose (non-empty) result TSV exists is skipped, as in the
     reference (:440-443) -- an empty one is what a killed run of the reference leaves behind
     (align_utterances.sh:105-107 deletes those) and is redone.  One failing file costs that file:
-    the round it was in is repeated file by file and the error is reported at the end."""
+    the round it was in is repeated file by file and the error is reported at the end.
+    ``speculate``: texts computed ahead with every DP request (``anchor.run_batched``; same results)."""
     from . import sharding
     samples_to_frames_ratio = aligner.estimate_samples_to_frames_ratio()
     paths = list(dict.fromkeys(df["Sample_Path"].tolist()))
@@ -135,7 +136,7 @@ def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params
     for k in range(0, len(todo), files_per_round):
         group = todo[k:k + files_per_round]
         try:
-            results = anchor.run_batched([coroutine_for(p) for p, _ in group], aligner)
+            results = anchor.run_batched([coroutine_for(p) for p, _ in group], aligner, speculate=speculate)
             for (audio_path, out), result in zip(group, results):
                 finish(audio_path, out, result)
         except Exception as exc:   # which file it was is not known in a lockstep round: redo it file by file
@@ -144,7 +145,7 @@ def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params
                 if out in written:
                     continue
                 try:
-                    finish(audio_path, out, anchor.run_batched([coroutine_for(audio_path)], aligner)[0])
+                    finish(audio_path, out, anchor.run_batched([coroutine_for(audio_path)], aligner, speculate=speculate)[0])
                 except Exception as one:
                     print("File {0} could not be aligned ({1}: {2}).".format(audio_path, type(one).__name__, one))
                     failed.append((audio_path, one))
@@ -432,6 +433,8 @@ def utterance_parser():
     p.add_argument("--window_to_stop", type=float, default=500.0)
     p.add_argument("--min_text_to_audio_prop", type=float, default=0.8)
     p.add_argument("--max_text_to_audio_prop_exec", type=int, default=10)
+    # not a flag of the reference: shrunk texts aligned ahead with every request (0 = one text per launch)
+    p.add_argument("--speculate", type=int, default=1)
     return p
 
 
@@ -450,7 +453,7 @@ def utterance_main(args, asr_model=None, aligner=None, opener=WavFile):
         max_text_to_audio_prop_exec=args.max_text_to_audio_prop_exec)
     rank, world = _rank_world()
     return align_utterance_files(asr_model, aligner, read_tsv(df_path), read_tsv(vad_path), args.dst,
-                                 args.logs_path, params, opener, rank, world)
+                                 args.logs_path, params, opener, rank, world, speculate=getattr(args, "speculate", 1))
 
 
 def word_parser(search=False):
