@@ -868,8 +868,13 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
         HIP_TRY(pl->eng, hipGetLastError());
         return CTCFA_OK;
     }
+#ifdef CTCFA_STAMP   // tuning builds: the tiles' cycle stamps land in the caller's char_prob buffer (tools/stamps2.py)
+    float* lastcol_arg = a.d_char_prob;
+#else
+    float* lastcol_arg = pl->d_lastcol[ws];
+#endif
     hipExtLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, start, stop, 0,
-                          pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], pl->d_lastcol[ws], pl->V, pl->prm.blank,
+                          pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], lastcol_arg, pl->V, pl->prm.blank,
                           (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0,
                           (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch);
     HIP_TRY(pl->eng, hipGetLastError());
@@ -878,6 +883,9 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
 
 int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hipStream_t st,
                      hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+#ifdef CTCFA_STAMP
+    return CTCFA_OK;   // (the stamps sit where the backtrack would write)
+#endif
     const bool windowed = !pl->win_list.empty();
     BtParams bp;
     bp.V = pl->V;

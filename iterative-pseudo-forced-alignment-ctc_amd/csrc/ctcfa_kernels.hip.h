@@ -48,6 +48,9 @@
 #ifndef CTCFA_VGPR_CAP
 #define CTCFA_VGPR_CAP 1
 #endif
+#ifndef CTCFA_ABL
+#define CTCFA_ABL 0   // tuning builds only (results are WRONG for > 0): parts of the group hand-over left out, to price them
+#endif
 #ifndef CTCFA_PF
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
 #endif
@@ -705,7 +708,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         }
 #pragma unroll
         for (int i = 0; i < kRows; ++i) {
-            if (i % kHaloRows == 0) {   // group start: the neighbour's columns replace what went wrong in my halo
+#if defined(CTCFA_STAMP) && CTCFA_STAMP >= 3   // where inside a block the cycles go: a stamp every 8 rows of block 40
+            if (i % 8 == 0 && j == 40 && lane == 0 && blockIdx.x < 64)
+                (reinterpret_cast<unsigned long long*>(lastcol) + 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[i / 8] = __builtin_amdgcn_s_memtime();
+#endif
+            if (i % kHaloRows == 0 && CTCFA_ABL < 2) {   // group start: the neighbour's columns replace what went wrong in my halo
 #pragma unroll
                 for (int k = 0; k < K; ++k) prev[k] = is_halo ? hx[k] : prev[k];
             }
@@ -761,13 +768,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int g = j * kGroups + i / kHaloRows;   // the group this row belongs to
             if (i % kHaloRows == kHaloRows - 1 - kPollLead - kPeekLead) {
                 // the counters are read a few rows before they are looked at: no LDS round trip in the way
-                if (w > 0) peek = flags[w - 1];
+                if (w > 0 && CTCFA_ABL < 1) peek = flags[w - 1];
                 if (i / kHaloRows == kGroups - 1) {   // (for the next block: no wait at its start)
                     peek_sa = flags[16];
                     peek_sb = flags[17];
                 }
             }
-            if (i % kHaloRows == kHaloRows - 1 - kPollLead) {
+            if (i % kHaloRows == kHaloRows - 1 - kPollLead && CTCFA_ABL < 2) {
                 if (w > 0) {   // my neighbour's columns at the end of this group, for my next one
 #if CTCFA_TILE_PRIO == 6
                     if (__builtin_amdgcn_readfirstlane(peek) < g + 1) __builtin_amdgcn_s_setprio(0);
@@ -786,7 +793,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     if (__builtin_amdgcn_readfirstlane(peek) < g + 1) __builtin_amdgcn_s_setprio(0);
                     else __builtin_amdgcn_s_setprio(2);
 #endif
-                    if (__builtin_expect(__builtin_amdgcn_readfirstlane(peek) < g + 1, 0)) {   // (normally it is 4+ rows ahead)
+                    if (CTCFA_ABL < 1 && __builtin_expect(__builtin_amdgcn_readfirstlane(peek) < g + 1, 0)) {   // (normally it is 4+ rows ahead)
                         CTCFA_STAMP_BEGIN();
                         int f, spins = 0;
                         do {
@@ -803,15 +810,21 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             }
             if (i % kHaloRows == kHaloRows - 1) {   // group end: my last columns for the tile to my right, then the counter
-                if (publishes) {
+                if (publishes && (CTCFA_ABL < 4 || i == kRows - 1)) {
                     float* xw = reinterpret_cast<float*>(smem + xout_addr + static_cast<uint32_t>((g % XR) * XW * 4));
+                    if (CTCFA_ABL < 3) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) xw[k] = prev[k];
+                        for (int k = 0; k < K; ++k) xw[k] = prev[k];
+                    }
                     asm volatile("" ::: "memory");
                     if (lane == 63) flags[w] = g + 1;
                 }
             }
         }
+#if defined(CTCFA_STAMP) && CTCFA_STAMP >= 3
+        if (j == 40 && lane == 0 && blockIdx.x < 64)
+            (reinterpret_cast<unsigned long long*>(lastcol) + 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[4] = __builtin_amdgcn_s_memtime();
+#endif
         // trace words of this block (fire and forget: this wave never waits on vmcnt); halo lanes hold
         // copies that have gone wrong by now
         if (lane >= HL) {

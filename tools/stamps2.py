@@ -39,6 +39,8 @@ for w in range(W):
     print(f"tile {w}: total {np.median(r[:,0]):.0f} cyc  nbr-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  "
           f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  in-rows {np.median(r[:,5]):.0f}  last block {np.median(r[:,6]):.0f}  "
           f"start +{np.median(r[:,7]-raw[:,0,7]):.0f}")
+if B * T * 4 < (64 + nb) * 16 * 8 * 8 or T <= 41 * 32:
+    sys.exit(0)
 raw2 = d_cp.cpu().numpy().view(np.uint64)[64 * 16 * 8: 64 * 16 * 8 + nb * 16 * 8].reshape(nb, 16, 8).astype(np.int64)
 for w in range(W):
     q = raw2[:, w, :5]
