@@ -440,8 +440,12 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     if (batch <= 0 || vocab <= 0) return set_err(eng, CTCFA_ERR_INVALID, "batch and vocab must be positive");
     if (params->blank < 0 || params->blank >= vocab) return set_err(eng, CTCFA_ERR_INVALID, "blank outside vocabulary");
     if (!(params->index_duration > 0.0)) return set_err(eng, CTCFA_ERR_INVALID, "index_duration must be > 0");
-    if (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO)
-        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero (gratis_blank) is not supported yet");
+    // blank_transition_cost_zero (gratis_blank): the fill charges nothing for staying in a column labelled
+    // blank while the package's backtrack still assumes max(blank, label) -- only checkpoint mode keeps
+    // the two apart (the decision words of the other mode are computed with the fill's step)
+    const bool gratis = (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) != 0;
+    if (gratis && vocab > 64)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero needs a vocabulary of at most 64 entries");
     if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > 128)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1,128]");
     // wide vocabularies (sub-word models) take the gather kernel: no LDS staging of vocabulary rows
@@ -449,6 +453,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     if (gather && !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO))
         return set_err(eng, CTCFA_ERR_UNSUPPORTED,
                        "vocab > 128 needs preamble_transition_cost_zero (the package default)");
+    if (gratis && gather)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero is not built for the wide-vocabulary fill kernel");
     DeviceGuard on_device(eng->device);
 
     ctcfa_plan* pl = new ctcfa_plan();
@@ -560,6 +566,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         const bool pays = use_scratch ? nf * Cmax >= 1024 * 1024
                                       : Cmax >= 544 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
+        if (gratis) pl->ckpt = true;   // (vocab <= 64 checked above)
     }
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
     int bt_lds_estimate;
@@ -875,7 +882,8 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
 #endif
     hipExtLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, start, stop, 0,
                           pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], lastcol_arg, pl->V, pl->prm.blank,
-                          (pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0,
+                          ((pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0) |
+                              ((pl->prm.flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) ? 2 : 0),
                           (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;

@@ -190,8 +190,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(((K <= 2 || (K == 3 && CK)) &
 __launch_bounds__((K >= 10) ? 320 : (K >= 8) ? 512 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
-            float* __restrict__ lastcol, int V, int blank, int preamble,
+            float* __restrict__ lastcol, int V, int blank, int cost_flags,
             const FillRoles* __restrict__ roles, const WatchDesc* __restrict__ watch) {
+    // cost_flags: bit 0 = preamble_transition_cost_zero (column 0 stays for free), bit 1 =
+    // blank_transition_cost_zero (a column labelled blank stays for free: the blank entry's m is 0)
+    const bool preamble = (cost_flags & 1) != 0;
+    const bool gratis = (cost_flags & 2) != 0;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int PITCH = VP + kPitchPad;  // row pitch in (e, m) entries; entry VP = start-column pseudo label
     constexpr int SLOT_BYTES = kRows * PITCH * 8;
@@ -328,7 +332,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const bool valid = t < T;
                 notneg |= !(e[q] <= 0.0f);
                 float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
-                if (sv < V) row[sv] = valid ? make_float2(e[q], max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
+                if (sv < V) row[sv] = valid ? make_float2(e[q], (gratis && sv == blank) ? 0.0f : max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
                 if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
                     row[VP] = make_float2(-__builtin_inff(),
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
@@ -369,6 +373,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const bool valid = (t0 + p * RPP) < T;
                     float4 lo = make_float4(v.x, max3f(lb, v.x, kProbMax), v.y, max3f(lb, v.y, kProbMax));
                     float4 hi = make_float4(v.z, max3f(lb, v.z, kProbMax), v.w, max3f(lb, v.w, kProbMax));
+                    if (gratis && lv == (blank & ~3)) {   // this lane holds the blank entry
+                        if (blank_comp == 0) lo.y = 0.0f;
+                        else if (blank_comp == 1) lo.w = 0.0f;
+                        else if (blank_comp == 2) hi.y = 0.0f;
+                        else hi.w = 0.0f;
+                    }
                     if (!valid) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
                     const float2 sp = make_float2(-__builtin_inff(),
                                                   (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
@@ -439,7 +449,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), blank));
                         const bool valid = (t0 + i * PARTS) < T;  // uniform
                         notneg |= !(e[i] <= 0.0f);
-                        float2 v = make_float2(e[i], max3f(lb, e[i], kProbMax));
+                        float2 v = make_float2(e[i], (gratis && svl == blank) ? 0.0f : max3f(lb, e[i], kProbMax));
                         if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
                         *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
@@ -522,8 +532,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                              : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1[r]), blank & 63));
                         const bool valid = (t0 + r * PARTS) < T;  // uniform
                         notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
-                        float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
-                        float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
+                        float2 v0 = make_float2(e0[r], (gratis && lane == blank) ? 0.0f : max3f(lb, e0[r], kProbMax));
+                        float2 v1 = make_float2(e1[r], (gratis && lane + 64 == blank) ? 0.0f : max3f(lb, e1[r], kProbMax));
                         float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         if (!valid) {
                             v0 = make_float2(0.f, 0.f);
@@ -1461,10 +1471,13 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
                 const uint32_t* seg_bits = bits + sd.bits_off;
                 const bool preamble = (p.flags & 2u) != 0;
-                auto cell = [&](float& prev, uint32_t& dec, float ee, float m) {
+                // m: the stay step the package's BACKTRACK assumes (max(blank, label)); mf: the one the FILL
+                // charged -- 0 in a column labelled blank under blank_transition_cost_zero, else m
+                const bool gratis = (p.flags & 1u) != 0;
+                auto cell = [&](float& prev, uint32_t& dec, float ee, float m, float mf) {
                     const float pl = dpp_wave_shl1(prev);
                     const float a = pl + ee;
-                    const float b = prev + m;
+                    const float b = prev + mf;
                     const float nw = max3f(a, b, kProbMax);
                     const float rsw = ee - (nw - pl);
                     const float rst = m - (nw - prev);
@@ -1496,7 +1509,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         const float e1 = lab < 0 ? -__builtin_inff() : ee[i];
                         const float m = lab < 0 ? (preamble ? 0.0f : __builtin_fmaxf(lb[i], kProbMax))
                                                 : max3f(lb[i], ee[i], kProbMax);
-                        cell(prev, dec, e1, m);
+                        cell(prev, dec, e1, m, (gratis && lab == p.blank) ? 0.0f : m);
                     }
                     return c <= 0 ? 0u : dec;  // start column and left of it: STAY
                 };
@@ -1562,7 +1575,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         if (j >= 1) {
                             uint32_t dec = 0u;
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y);
+                            for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y, (gratis && lab == p.blank) ? 0.0f : emr[i].y);
                             wbuf[lane] = c <= 0 ? 0u : dec;
                         }
                         --j;
@@ -1910,6 +1923,7 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                             b = pcand > pm ? pcand : pm;           // switch_prob = max(prob_max, p)
                             const float mlpz = e > pm ? e : pm;    // max_lpz_prob
                             m = mlpz > lb ? mlpz : lb;             // max(lpz[blank], max_lpz_prob)
+                            if ((p.flags & 1u) && g == p.blank) m = 0.0f;   // blank_transition_cost_zero
                         } else {
                             b = (t == 0) ? 0.0f : pm;              // table[0,0] = 0; no switch into column 0
                             m = preamble ? 0.0f : (pm > lb ? pm : lb);

@@ -827,3 +827,38 @@ def test_one_over_long_text_is_that_segments_status(pkg, oracle, engine):
         pkg.ctc_segmentation._raise_for_status(res[1]["status"])
     with pytest.raises(AssertionError):
         pkg.ctc_segmentation._raise_for_status(res[3]["status"])
+
+
+@pytest.mark.parametrize("V", [32, 38, 64])
+def test_blank_transition_cost_zero(pkg, oracle, V):
+    """gratis_blank / config.blank_transition_cost_zero -- the knob both test scripts of the reference
+    set (src/test/test_ctc_segmentation.py:31, src/test/test_seq2seq_segmentation.py:24): a column
+    labelled blank (every utterance separator) stays for free in the fill, while the backtrack still
+    infers transitions against max(blank, label).  Also with test_ctc_segmentation.py's other knobs
+    (backtrack_from_max_t), in the windowed regime and with texts that share a fill."""
+    syn = pkg.synthetic
+    rng = np.random.default_rng(77 + V)
+    segs = []
+    for s in range(10):
+        T = int(rng.integers(50, 1300))
+        U = int(rng.integers(1, 8))
+        n = int(rng.integers(2, max(3, min(30, (T - 3) // (U + 1) - 1))))
+        segs.append(syn.make_segment(1200 + s + V, T, V, U, n))
+    kw = dict(blank_transition_cost_zero=True)
+    _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+    kw2 = dict(blank_transition_cost_zero=True, backtrack_from_max_t=True)
+    _check(pkg, oracle, segs, _run(pkg, segs, **kw2), cfg_kw=kw2)
+    kw3 = dict(blank_transition_cost_zero=True, preamble_transition_cost_zero=False)
+    _check(pkg, oracle, segs, _run(pkg, segs, **kw3), cfg_kw=kw3)
+    kw4 = dict(blank_transition_cost_zero=True, min_window_size=120, max_window_size=4000)
+    _check(pkg, oracle, segs, _run(pkg, segs, **kw4), cfg_kw=kw4)
+    # the window's text and the text minus its last utterances over the same emissions: one fill
+    lpz, gt, ub = syn.make_segment(1300 + V, 700, V, 6, 18)
+    members = [(lpz, gt[:ub[k] + 1].copy(), ub[:k + 1].copy()) for k in range(6, 0, -1)]
+    _check(pkg, oracle, members, _run(pkg, members, **kw), cfg_kw=kw)
+
+
+def test_blank_transition_cost_zero_beyond_64_entries_is_refused(pkg):
+    segs = [pkg.synthetic.make_segment(5, 200, 100, 2, 10)]
+    with pytest.raises(NotImplementedError):
+        _run(pkg, segs, blank_transition_cost_zero=True)
