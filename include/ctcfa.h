@@ -205,6 +205,21 @@ int ctcfa_align_batch_shared(ctcfa_engine* eng, const ctcfa_params* params, int3
                              double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
                              int32_t* status, void* stream);
 
+/*
+ * LABEL MATRICES (multi-character tokens): `label_matrix` is ground_truth_mat itself, int32
+ * [C_b, label_width] row-major per segment, -1 padded -- entry [c, s] = id of the token made of the
+ * s + 1 characters ending in column c (ctc_segmentation.prepare_text, the "classic" text converter of
+ * SpeechBrain's CTCSegmentation).  A token of s + 1 characters enters column c from column c - (s + 1)
+ * in one frame step (cython_fill_table's loop over s; the backtrack's min_s).  label_width in [1,16];
+ * every segment goes through the literal, sequential windowed kernel (any T up to ~40 000 frames):
+ * exact, not fast.  Otherwise as ctcfa_align_batch (frame_of_label has C_b entries per segment).
+ */
+int ctcfa_align_batch_spans(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                            int32_t label_width, const int32_t* T, const int32_t* C, const int32_t* U,
+                            const float* lpz, const int32_t* label_matrix, const int32_t* utt_begin,
+                            int32_t* frame_of_label, float* char_prob, int32_t* state, double* seg_start,
+                            double* seg_end, double* seg_score, int32_t* t_end, int32_t* status);
+
 /* Plan for the same geometry (ctcfa_plan_run_device / _pipelined then take `d_lpz` with the shared
  * blocks once).  labels: HOST array of all segments' labels back to back, used to check the prefix
  * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes. */

@@ -26,7 +26,7 @@ EXPORTS = (
     "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_run_pipelined", "ctcfa_plan_flush",
     "ctcfa_plan_get_timings",
     "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch", "ctcfa_align_batch_resident",
-    "ctcfa_align_batch_shared", "ctcfa_plan_create_shared", "ctcfa_plan_get_sharing",
+    "ctcfa_align_batch_shared", "ctcfa_plan_create_shared", "ctcfa_plan_get_sharing", "ctcfa_align_batch_spans",
 )
 
 
@@ -109,6 +109,8 @@ def load():
     lib.ctcfa_plan_create_shared.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(Params), ctypes.c_int32,
                                              ctypes.c_int32, i32p, i32p, i32p, i32p, i32p, ctypes.c_int32]
     lib.ctcfa_plan_get_sharing.argtypes = [vp, i32p, i32p]
+    lib.ctcfa_align_batch_spans.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                            i32p, i32p, i32p] + [vp] * 11
     _lib = lib
     return lib
 
@@ -166,7 +168,7 @@ class Engine:
             raise exc(f"{what} failed ({rc}): {msg}")
 
     def align_batch(self, params, lpz_list, labels_list, utt_begin_list=None, want_state=True, d_lpz=None,
-                    stream=None, shapes=None, emission_of=None):
+                    stream=None, shapes=None, emission_of=None, label_width=1):
         """Host-buffer entry ``ctcfa_align_batch``, or -- with ``d_lpz`` (device address of the
         concatenated fp32 emissions) and ``shapes`` = [(T_b, V), ...] -- ``ctcfa_align_batch_resident``.
 
@@ -176,12 +178,17 @@ class Engine:
         emission_of (``ctcfa_align_batch_shared``): emission_of[b] = index of the segment whose
         emissions segment b uses; only the blocks of segments with emission_of[b] == b are read from
         ``lpz_list`` / expected at ``d_lpz`` (``shapes`` still lists every segment).
+
+        label_width = S > 1 (``ctcfa_align_batch_spans``, host emissions only): every entry of
+        ``labels_list`` is a label matrix int [C_b, S] (ground_truth_mat, -1 padded).
         """
         shapes = shapes or [l.shape for l in lpz_list]
         B = len(shapes)
         V = int(shapes[0][1])
         T = _i32([sh[0] for sh in shapes])
         C = _i32([len(g) for g in labels_list])
+        if label_width > 1 and (d_lpz is not None or emission_of is not None):
+            raise ValueError("label matrices take host emissions of their own")
         if emission_of is not None:
             emission_of = _i32(emission_of)
             if len(emission_of) != B:
@@ -207,7 +214,11 @@ class Engine:
         tail = (_ptr(labels), _ptr(ub), _ptr(fol), _ptr(cp), _ptr(state),
                 _ptr(seg[0]) if have_utt else None, _ptr(seg[1]) if have_utt else None,
                 _ptr(seg[2]) if have_utt else None, _ptr(t_end), _ptr(status))
-        if emission_of is not None:
+        if label_width > 1:
+            rc = self._lib.ctcfa_align_batch_spans(self._h, ctypes.byref(params), B, V, int(label_width), _i32p(T), _i32p(C),
+                                                   _i32p(U), _ptr(lpz), *tail)
+            self._check(rc, "ctcfa_align_batch_spans")
+        elif emission_of is not None:
             rc = self._lib.ctcfa_align_batch_shared(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
                                                     _i32p(emission_of),
                                                     _ptr(lpz) if d_lpz is None else ctypes.c_void_p(int(d_lpz)),

@@ -77,6 +77,7 @@ struct ctcfa_plan {
     std::vector<ctcfa::WatchDesc> watch;
     ctcfa::WatchDesc* d_watch = nullptr;
     int nwatch_max = 0;
+    int S = 1;                        // label width (> 1: multi-character tokens, every segment through windowed_kernel)
     int n_fill = 0;                   // segments that get a fill workgroup of their own
     int64_t total_lpz_T = 0;
     // windowed regime (T > min_window_size): segment indices, fp32 table + per-column offsets
@@ -434,7 +435,10 @@ hipError_t scratch_get(ctcfa_engine* eng, int slot, void** p, size_t bytes) {
 int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
                      int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
                      int32_t force_k, bool use_scratch, const int32_t* emission_of = nullptr,
-                     const int32_t* labels = nullptr) {
+                     const int32_t* labels = nullptr, int32_t label_width = 1) {
+    if (label_width < 1 || label_width > ctcfa::kMaxSpan)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "label_width must be in [1,16]");
+    if (label_width > 1) emission_of = nullptr;   // (no shared fills for label matrices; callers pass none)
     if (!eng || !out || !params || !T || !C) return set_err(eng, CTCFA_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (batch <= 0 || vocab <= 0) return set_err(eng, CTCFA_ERR_INVALID, "batch and vocab must be positive");
@@ -462,6 +466,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->prm = *params;
     pl->B = batch;
     pl->V = vocab;
+    pl->S = label_width;
     // LDS row pitch: the vocabulary rounded up to a compiled size.  Character vocabularies of
     // wav2vec2 models sit between 32 and 64 (the reference's Spanish model: 38 tokens), where
     // a pitch of 64 would cost a second workgroup per CU.
@@ -507,7 +512,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     int Cmax = 2, Tmax = 1;
     for (int b = 0; b < batch; ++b) {
         if (C[b] > T[b]) pre[b] = CTCFA_ST_AUDIO_SHORTER_THAN_TEXT;
-        else if (T[b] > params->min_window_size)
+        else if (T[b] > params->min_window_size || label_width > 1)   // label matrices: the literal (windowed) kernel, any T
             pre[b] = ((int64_t)T[b] * 4 > lds_dyn_max) ? CTCFA_ST_WINDOWED_UNSUPPORTED : ctcfa::kPreWindowed;
         else if (C[b] > c_limit) pre[b] = CTCFA_ST_TEXT_TOO_LONG;
         if (pre[b] == CTCFA_ST_OK) {
@@ -930,6 +935,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.min_window = pl->prm.min_window_size;
         wp.max_window = pl->prm.max_window_size;
         wp.lds_bytes = pl->lds_win;
+        wp.S = pl->S;
         wp.dur = pl->prm.index_duration;
         hipExtLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
                               pl->lds_win, st, nullptr, stop, 0, (const SegDesc*)pl->d_segs,
@@ -1062,14 +1068,15 @@ hipError_t pinned_get(unsigned char** p, size_t* cap, size_t bytes) {
 // kernels, ONE result download.  An anchor iteration issues hundreds of such calls for windows of a
 // few hundred frames: what a call costs beyond its kernels is what this function keeps small.
 int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab, const int32_t* T,
-               const int32_t* C, const int32_t* U, const int32_t* emission_of, const float* host_lpz,
-               const float* dev_lpz, hipStream_t st,
+               const int32_t* C, const int32_t* U, const int32_t* emission_of, int32_t label_width,
+               const float* host_lpz, const float* dev_lpz, hipStream_t st,
                const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label, float* char_prob,
                int32_t* state, double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
                int32_t* status) {
     DeviceGuard on_device(eng->device);
     ctcfa_plan* pl = nullptr;
-    int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of, labels);
+    int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of,
+                              label_width > 1 ? nullptr : labels, label_width);
     if (rc != CTCFA_OK) return rc;
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
     const size_t n_lpz = (size_t)pl->total_lpz_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
@@ -1091,7 +1098,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     // packed upload: role table | segment table | labels | utterance starts | watch columns of shared fills
     const size_t n_watch = pl->watch.size();
     const size_t in_roles = 0, in_segs = up(sizeof(ctcfa::FillRoles)), in_lab = in_segs + up(sizeof(SegDesc) * (size_t)batch),
-                 in_ub = in_lab + up(n_lab * 4), in_watch = in_ub + (want_seg ? up(n_ub * 4) : 0),
+                 in_ub = in_lab + up(n_lab * 4 * (size_t)pl->S), in_watch = in_ub + (want_seg ? up(n_ub * 4) : 0),
                  in_bytes = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc));
     const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
                  o_tend = o_state + (state ? up(n_frm * 4) : 0), o_status = o_tend + up((size_t)batch * 4),
@@ -1106,7 +1113,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     unsigned char* h = eng->h_in;
     std::memcpy(h + in_roles, &pl->roles, sizeof(ctcfa::FillRoles));
     std::memcpy(h + in_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch);
-    std::memcpy(h + in_lab, labels, n_lab * 4);
+    std::memcpy(h + in_lab, labels, n_lab * 4 * (size_t)pl->S);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
     if (n_watch) std::memcpy(h + in_watch, pl->watch.data(), n_watch * sizeof(ctcfa::WatchDesc));
     AB_TRY(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, st));
@@ -1154,7 +1161,7 @@ int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t bat
     if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
     if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
-    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, lpz, nullptr, eng->stream, labels, utt_begin,
+    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, 1, lpz, nullptr, eng->stream, labels, utt_begin,
                       frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
 }
 
@@ -1166,7 +1173,7 @@ int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, in
     if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
     if (!d_lpz || !labels || !frame_of_label || !char_prob || !t_end || !status)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL buffer");
-    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, nullptr, d_lpz, reinterpret_cast<hipStream_t>(stream),
+    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, 1, nullptr, d_lpz, reinterpret_cast<hipStream_t>(stream),
                       labels, utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
 }
 
@@ -1179,9 +1186,21 @@ int ctcfa_align_batch_shared(ctcfa_engine* eng, const ctcfa_params* params, int3
     if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
     if (!lpz || !labels || !frame_of_label || !char_prob || !t_end || !status || !emission_of)
         return set_err(eng, CTCFA_ERR_INVALID, "NULL buffer");
-    return align_impl(eng, params, batch, vocab, T, C, U, emission_of, lpz_on_device ? nullptr : lpz,
+    return align_impl(eng, params, batch, vocab, T, C, U, emission_of, 1, lpz_on_device ? nullptr : lpz,
                       lpz_on_device ? lpz : nullptr, lpz_on_device ? reinterpret_cast<hipStream_t>(stream) : eng->stream,
                       labels, utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
+}
+
+int ctcfa_align_batch_spans(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
+                            int32_t label_width, const int32_t* T, const int32_t* C, const int32_t* U,
+                            const float* lpz, const int32_t* label_matrix, const int32_t* utt_begin,
+                            int32_t* frame_of_label, float* char_prob, int32_t* state, double* seg_start,
+                            double* seg_end, double* seg_score, int32_t* t_end, int32_t* status) {
+    if (!eng) return set_err(nullptr, CTCFA_ERR_INVALID, "engine == NULL");
+    if (!lpz || !label_matrix || !frame_of_label || !char_prob || !t_end || !status)
+        return set_err(eng, CTCFA_ERR_INVALID, "NULL host buffer");
+    return align_impl(eng, params, batch, vocab, T, C, U, nullptr, label_width, lpz, nullptr, eng->stream, label_matrix,
+                      utt_begin, frame_of_label, char_prob, state, seg_start, seg_end, seg_score, t_end, status);
 }
 
 int ctcfa_plan_create_shared(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,

@@ -1796,8 +1796,10 @@ struct WinParams {
     int L;
     int min_window, max_window;
     int lds_bytes;  // dynamic LDS given to the kernel
+    int S;          // label width: ground_truth_mat[:, 0..S-1] (tokens of 1..S characters ending in a column); 1 = single labels
     double dur;
 };
+constexpr int kMaxSpan = 16;   // widest label matrix the windowed kernel takes
 
 __device__ __forceinline__ int64_t np_index(int64_t i, int64_t n, int& err) {
     if (i < 0) i += n;
@@ -1825,8 +1827,9 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SegDesc sd = segs[win_list[blockIdx.x]];
     const int T = sd.T, C = sd.C, U = sd.U, V = p.V;
+    const int S = p.S;   // label matrix [C, S] row-major, -1 padded (S == 1: the plain label sequence)
     const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
-    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off * S;
     int32_t* fol = frame_of_label + sd.lab_off;
     float* cp = char_prob + sd.frm_off;
     int32_t* st = state ? state + sd.frm_off : nullptr;
@@ -1847,6 +1850,11 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
             cp[t] = 0.0f;
             if (st) st[t] = -2;
         }
+        if (S > 1) {   // multi-character tokens read columns through Cython's index wrap-around: cells no
+                       // column has reached yet must hold what `table.fill(config.max_prob)` left there
+            for (int64_t i = tid; i < (int64_t)W * C; i += kWinThreads) table[i] = kMaxProb;
+            __threadfence();
+        }
         __syncthreads();
         // Two column buffers when they fit: wave 0 then never stores to HBM (vmcnt retires in
         // order on gfx9 -- its emission prefetch would wait for the previous chunk's table store in
@@ -1857,6 +1865,9 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
         const float mean_offset = (float)((double)(T - W) / (double)C);
         const int higher_offset = (int)mean_offset + 1;
         int offset_sum = 0, last_arg = -1;
+        int cur_off[kMaxSpan];   // cur_offset[s] of cython_fill_table (wave-uniform)
+#pragma unroll
+        for (int q = 0; q < kMaxSpan; ++q) cur_off[q] = -1;
         const int nchunk = (W + 63) / 64;
         for (int c = 0; c < C; ++c) {
             float* colw = col + ((dbl && (c & 1)) ? W : 0);         // this column
@@ -1870,9 +1881,13 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                     if (higher_offset < b) b = higher_offset;
                     off = a < b ? a : b;
                     offset_sum += off;
+#pragma unroll
+                    for (int q = 0; q + 1 < kMaxSpan; ++q)   // in place, ascending, as the package does it
+                        if (q + 1 < S) cur_off[q + 1] = cur_off[q] + off;
+                    cur_off[0] = off;
                 }
                 if (lane == 0) __hip_atomic_store(offsets + c, offset_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int g = seg_lab[c];  // -1 for c == 0
+                const int g = seg_lab[(int64_t)c * S];  // -1 for c == 0 (and where no one-character token ends)
                 // first maximum of the column: every lane keeps the best of its own rows (ascending t,
                 // strict '>' keeps the first), the lanes are reduced once per column
                 float best_v = -__builtin_inff();
@@ -1894,7 +1909,7 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                     // raw loads only (any arithmetic on the results here would make the wave wait
                     // for them a chunk early); column 0 has no label: read the blank entry, unused
                     lb_out = seg_lpz[(int64_t)f * V + p.blank];
-                    e_out = seg_lpz[(int64_t)f * V + (c > 0 ? g : p.blank)];
+                    e_out = seg_lpz[(int64_t)f * V + ((c > 0 && g >= 0) ? g : p.blank)];
                 };
                 // Chunks go in groups of G: the emissions of the NEXT group are requested at the top of
                 // a group (the compiler drains vmcnt at the loop's back edge, so a group has to be
@@ -1917,11 +1932,39 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                         const float lb = lb_cur[q];
                         float b, m;
                         if (c > 0) {
-                            const float e = e_cur[q];
-                            const int r = t - 1 + off;
-                            const float pcand = (r >= W || r < 0) ? pm : pin + e;
-                            b = pcand > pm ? pcand : pm;           // switch_prob = max(prob_max, p)
-                            const float mlpz = e > pm ? e : pm;    // max_lpz_prob
+                            b = pm;              // switch_prob
+                            float mlpz = pm;     // max_lpz_prob
+                            if (g >= 0) {
+                                const float e = e_cur[q];
+                                const int r = t - 1 + off;
+                                const float pcand = (r >= W || r < 0) ? pm : pin + e;
+                                b = pcand > pm ? pcand : pm;           // switch_prob = max(prob_max, p)
+                                mlpz = e > pm ? e : pm;
+                            }
+                            // tokens of s + 1 characters ending in this column: they leave column c - (s + 1)
+                            // (an index below 0 wraps, as in Cython) in the same frame step
+                            for (int sp = 1; sp < S; ++sp) {
+                                const int gs = seg_lab[(int64_t)c * S + sp];
+                                if (gs < 0) continue;   // uniform
+                                const int f = valid ? t + offset_sum : T - 1;
+                                const float es = seg_lpz[(int64_t)f * V + gs];
+                                int co = -1;
+#pragma unroll
+                                for (int z = 1; z < kMaxSpan; ++z) co = (z == sp) ? cur_off[z] : co;
+                                float ps;
+                                if (t >= W - (co - 1) || t - 1 + co < 0) {
+                                    ps = pm;
+                                } else {
+                                    int pcw = c - (sp + 1);
+                                    if (pcw < 0) pcw += C;
+                                    ps = __hip_atomic_load(table + (int64_t)pcw * W + (t - 1 + co), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT) + es;
+                                }
+                                if (valid) {
+                                    b = ps > b ? ps : b;
+                                    mlpz = es > mlpz ? es : mlpz;
+                                }
+                            }
                             m = mlpz > lb ? mlpz : lb;             // max(lpz[blank], max_lpz_prob)
                             if ((p.flags & 1u) && g == p.blank) m = 0.0f;   // blank_transition_cost_zero
                         } else {
@@ -2003,38 +2046,42 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                     bool max_lpz_f32 = false;
                     const int64_t cw = np_index(c, C, err);
                     if (err) break;
-                    const int g = seg_lab[cw];
-                    if (g != -1) {
-                        const int64_t pc = np_index(c - 1, C, err);
+                    int g = -1;   // ground_truth[c, min_s]
+                    for (int sp = 0; sp < S && !err; ++sp) {
+                        const int gs = seg_lab[cw * S + sp];
+                        if (gs == -1) continue;
+                        const int64_t pc = np_index(c - 1 - sp, C, err);
                         if (err) break;
-                        offset = offs(cw) - ((c > 0) ? offs(pc) : 0);
-                        double sp;
+                        offset = offs(cw) - ((c - sp > 0) ? offs(pc) : 0);   // (the last s looked at leaves its value behind, as in the package)
+                        double sp_prob;
                         bool sp_f32 = false;
                         if (c > 0) {
                             const int64_t r = np_index(t + offs(cw), T, err);
-                            const int64_t gi = np_index(g, V, err);
+                            const int64_t gi = np_index(gs, V, err);
                             if (err) break;
-                            sp = (double)seg_lpz[r * V + gi];
+                            sp_prob = (double)seg_lpz[r * V + gi];
                             sp_f32 = true;
                         } else {
-                            sp = max_prob;
+                            sp_prob = max_prob;
                         }
                         const int64_t r0 = np_index(t, W, err);
                         const int64_t r1 = np_index(t - 1 + offset, W, err);
                         if (err) break;
                         const float est32 = tab(r0, cw) - tab(r1, pc);
                         double delta;
-                        if (sp_f32) delta = (double)__builtin_fabsf((float)sp - est32);
-                        else delta = __builtin_fabs(sp - (double)est32);
+                        if (sp_f32) delta = (double)__builtin_fabsf((float)sp_prob - est32);
+                        else delta = __builtin_fabs(sp_prob - (double)est32);
                         if (delta < min_delta) {
                             min_delta = delta;
-                            min_s = 0;
+                            min_s = sp;
+                            g = gs;
                         }
-                        if (sp > max_lpz) {
-                            max_lpz = sp;
+                        if (sp_prob > max_lpz) {
+                            max_lpz = sp_prob;
                             max_lpz_f32 = sp_f32;
                         }
                     }
+                    if (err) break;
                     double stay;
                     bool stay_f32 = false;
                     if (t > 0) {
@@ -2062,9 +2109,11 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                         if (c > 0) {
                             const int64_t fr = np_index(offs(cw) + t, T, err);
                             if (err) break;
-                            const int64_t ci = np_index(c, C, err);  // s = 0 .. min_s with min_s == 0
+                            for (int sp = 0; sp <= min_s && !err; ++sp) {   // every character of the token
+                                const int64_t ci = np_index(c - sp, C, err);
+                                if (!err) fol[ci] = (int32_t)(offs(cw) + t);
+                            }
                             if (err) break;
-                            fol[ci] = (int32_t)(offs(cw) + t);
                             cp[fr] = (float)max_lpz;
                             if (st) st[fr] = g;
                         }

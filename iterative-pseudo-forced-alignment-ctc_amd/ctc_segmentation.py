@@ -166,14 +166,43 @@ def default_engine(device=0):
 
 
 def _labels_from_mat(ground_truth):
+    """ground_truth_mat -> the label sequence int32 [C] -- or, when tokens of more than one character
+    occur in it (columns 1.. not all -1: the "classic" text converter), the matrix int32 [C, S]."""
     gt = np.asarray(ground_truth)
     if gt.ndim == 2:
-        if gt.shape[1] != 1:
-            # multi-character tokens (S > 1) need the second kernel variant
-            if (gt[:, 1:] != -1).any():
-                raise NotImplementedError("ground truth with multi-character tokens (S > 1)")
+        if gt.shape[1] != 1 and (gt[:, 1:] != -1).any():
+            used = 1 + int(np.nonzero((gt[:, 1:] != -1).any(axis=0))[0].max())
+            return np.ascontiguousarray(gt[:, :used + 1], dtype=np.int32)
         gt = gt[:, 0]
     return np.ascontiguousarray(gt, dtype=np.int32)
+
+
+MAX_LABEL_WIDTH = 16   # ctcfa::kMaxSpan
+
+
+def _align_label_matrices(engine, config, lpz_list, labels, utt_begin_list, want_state):
+    """Segments whose ground truth holds multi-character tokens: ``ctcfa_align_batch_spans`` (the
+    literal, sequential kernel)."""
+    S = max(g.shape[1] if g.ndim == 2 else 1 for g in labels)
+    if S > MAX_LABEL_WIDTH:
+        raise NotImplementedError(f"tokens of more than {MAX_LABEL_WIDTH} characters")
+    V = int(lpz_list[0].shape[1])
+    mats = []
+    for b, g in enumerate(labels):
+        m = np.full((len(g), S), -1, np.int32)
+        if g.ndim == 2:
+            m[:, :g.shape[1]] = g
+        else:
+            m[:, 0] = g
+        if len(m) < 2 or (m[0] != -1).any():
+            raise ValueError(f"segment {b}: ground truth must start with a row of -1 and hold at least one more")
+        if int(m.min()) < -1 or int(m.max()) >= V:
+            raise IndexError(f"segment {b}: label id outside the vocabulary [0, {V})")
+        mats.append(m)
+    # (emission shapes and utterance starts: the checks of the single-label path, on a stand-in sequence of the same length)
+    _validate_segments(lpz_list, [np.r_[-1, np.zeros(len(m) - 1, np.int32)].astype(np.int32) for m in mats], utt_begin_list)
+    lpz_list = [np.ascontiguousarray(l.cpu().numpy() if hasattr(l, "cpu") else l, dtype=np.float32) for l in lpz_list]
+    return engine.align_batch(config.to_native(), lpz_list, mats, utt_begin_list, want_state=want_state, label_width=S)
 
 
 def _raise_for_status(status):
@@ -233,6 +262,8 @@ def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, eng
     """
     engine = engine or default_engine()
     labels = [_labels_from_mat(g) for g in ground_truth_list]
+    if any(g.ndim == 2 for g in labels):
+        return _align_label_matrices(engine, config, lpz_list, labels, utt_begin_list, want_state)
     _validate_segments(lpz_list, labels, utt_begin_list)
     emission_of = shared_emissions(lpz_list)
     if lpz_list and all(_is_device_tensor(l) for l in lpz_list):
