@@ -215,12 +215,16 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
     frames_step = frames_override if frames_override is not None else sum(g["frames"] for g in G)
     pipelined = not args.serial and not sequential
 
+    for g in G:   # (argument conversion once per output slot, not per launch)
+        g["run"] = [g["plan"].bind(g["lpz"].data_ptr(), g["lab"].data_ptr(), g["ub"].data_ptr(), o["fol"].data_ptr(),
+                                   o["cp"].data_ptr(), None, o["seg"][0].data_ptr(), o["seg"][1].data_ptr(),
+                                   o["seg"][2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(), stream.cuda_stream,
+                                   pipelined=pipelined) for o in g["outs"]]
+
     def run_group(g):
         o = g["outs"][g["n"] % 3]
+        g["run"][g["n"] % 3]()
         g["n"] += 1
-        g["plan"].run_device(g["lpz"].data_ptr(), g["lab"].data_ptr(), g["ub"].data_ptr(), o["fol"].data_ptr(),
-                             o["cp"].data_ptr(), None, o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(),
-                             o["te"].data_ptr(), o["status"].data_ptr(), stream.cuda_stream, pipelined=pipelined)
         if sequential:   # the state machine reads this round's scores before it can form the next window
             g["host"].copy_(o["seg"], non_blocking=True)
             stream.synchronize()

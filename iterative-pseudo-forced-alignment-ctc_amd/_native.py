@@ -167,6 +167,37 @@ class Engine:
             exc = NotImplementedError if rc == ERR_UNSUPPORTED else (ValueError if rc == ERR_INVALID else NativeLibraryError)
             raise exc(f"{what} failed ({rc}): {msg}")
 
+    # Host-side staging of the host-buffer entries: grow-only NumPy buffers whose addresses are turned into
+    # ctypes pointers once (``ndarray.ctypes`` costs microseconds per use -- with a dozen arguments per call that
+    # was as long as the kernels of a 10 s window).  Results are copied out of them, so a call's result
+    # arrays stay valid after the next call.
+    def _staging(self, B, nT, nC, nU, nL, nB):
+        st = getattr(self, "_st", None)
+        if st is None or st["B"] < B or st["T"] < nT or st["C"] < nC or st["U"] < nU or st["L"] < nL or st["UB"] < nB:
+            grow = lambda need, old: max(need + need // 2 + 16, old)
+            o = st or dict(B=0, T=0, C=0, U=0, L=0, UB=0)
+            cap = dict(B=grow(B, o["B"]), T=grow(nT, o["T"]), C=grow(nC, o["C"]), U=grow(nU, o["U"]), L=grow(nL, o["L"]),
+                       UB=grow(nB, o["UB"]))
+            st = dict(cap)
+            st["Tn"] = np.zeros(cap["B"], np.int32)
+            st["Cn"] = np.zeros(cap["B"], np.int32)
+            st["Un"] = np.zeros(cap["B"], np.int32)
+            st["em"] = np.zeros(cap["B"], np.int32)
+            st["lab"] = np.zeros(cap["L"], np.int32)
+            st["ub"] = np.zeros(cap["UB"], np.int32)
+            st["fol"] = np.zeros(cap["C"], np.int32)
+            st["cp"] = np.zeros(cap["T"], np.float32)
+            st["state"] = np.zeros(cap["T"], np.int32)
+            st["seg"] = np.zeros((3, cap["U"]), np.float64)
+            st["t_end"] = np.zeros(cap["B"], np.int32)
+            st["status"] = np.zeros(cap["B"], np.int32)
+            i32 = ctypes.POINTER(ctypes.c_int32)
+            st["p"] = {k: st[k].ctypes.data_as(i32) for k in ("Tn", "Cn", "Un", "em")}
+            st["p"].update({k: st[k].ctypes.data_as(ctypes.c_void_p) for k in ("lab", "ub", "fol", "cp", "state", "t_end", "status")})
+            st["p"]["seg"] = [st["seg"][r].ctypes.data_as(ctypes.c_void_p) for r in range(3)]
+            self._st = st
+        return st
+
     def align_batch(self, params, lpz_list, labels_list, utt_begin_list=None, want_state=True, d_lpz=None,
                     stream=None, shapes=None, emission_of=None, label_width=1):
         """Host-buffer entry ``ctcfa_align_batch``, or -- with ``d_lpz`` (device address of the
@@ -185,68 +216,81 @@ class Engine:
         shapes = shapes or [l.shape for l in lpz_list]
         B = len(shapes)
         V = int(shapes[0][1])
-        T = _i32([sh[0] for sh in shapes])
-        C = _i32([len(g) for g in labels_list])
-        if label_width > 1 and (d_lpz is not None or emission_of is not None):
+        S = int(label_width)
+        if S > 1 and (d_lpz is not None or emission_of is not None):
             raise ValueError("label matrices take host emissions of their own")
+        have_utt = utt_begin_list is not None
+        Ts = [int(sh[0]) for sh in shapes]
+        Cs = [len(g) for g in labels_list]
+        Us = [len(u) - 1 for u in utt_begin_list] if have_utt else None
+        nT, nC = sum(Ts), sum(Cs)
+        nU = sum(Us) if have_utt else 0
         if emission_of is not None:
-            emission_of = _i32(emission_of)
             if len(emission_of) != B:
                 raise ValueError("emission_of must have one entry per segment")
             if all(int(e) == b for b, e in enumerate(emission_of)):
                 emission_of = None
+        st = self._staging(B, nT, nC, max(nU, 1), nC * S, nU + B)
+        p = st["p"]
+        st["Tn"][:B] = Ts
+        st["Cn"][:B] = Cs
+        if have_utt:
+            st["Un"][:B] = Us
+        if emission_of is not None:
+            st["em"][:B] = emission_of
+        o = 0
+        for g in labels_list:
+            n = len(g) * S
+            st["lab"][o:o + n] = np.asarray(g).reshape(-1)
+            o += n
+        if have_utt:
+            o = 0
+            for u in utt_begin_list:
+                st["ub"][o:o + len(u)] = u
+                o += len(u)
         if d_lpz is None:
             own = [l for b, l in enumerate(lpz_list) if emission_of is None or int(emission_of[b]) == b]
-            lpz = own[0].reshape(-1) if len(own) == 1 else np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in own])
+            lpz = own[0] if len(own) == 1 else np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in own])
             lpz = np.ascontiguousarray(lpz, dtype=np.float32)
-        labels = _i32(labels_list[0]) if B == 1 else _i32(np.concatenate([np.asarray(g).reshape(-1) for g in labels_list]))
-        have_utt = utt_begin_list is not None
-        U = _i32([len(u) - 1 for u in utt_begin_list]) if have_utt else None
-        ub = _i32(np.concatenate([np.asarray(u).reshape(-1) for u in utt_begin_list])) if have_utt else None
-        nT, nC = int(T.sum()), int(C.sum())
-        nU = int(U.sum()) if have_utt else 0
-        fol = np.zeros(nC, np.int32)
-        cp = np.zeros(nT, np.float32)
-        state = np.zeros(nT, np.int32) if want_state else None
-        seg = np.zeros((3, max(nU, 1)), np.float64) if have_utt else None
-        t_end = np.zeros(B, np.int32)
-        status = np.zeros(B, np.int32)
-        tail = (_ptr(labels), _ptr(ub), _ptr(fol), _ptr(cp), _ptr(state),
-                _ptr(seg[0]) if have_utt else None, _ptr(seg[1]) if have_utt else None,
-                _ptr(seg[2]) if have_utt else None, _ptr(t_end), _ptr(status))
-        if label_width > 1:
-            rc = self._lib.ctcfa_align_batch_spans(self._h, ctypes.byref(params), B, V, int(label_width), _i32p(T), _i32p(C),
-                                                   _i32p(U), _ptr(lpz), *tail)
+            lpz_arg = ctypes.c_void_p(lpz.ctypes.data)
+        else:
+            lpz_arg = ctypes.c_void_p(int(d_lpz))
+        tail = (p["lab"], p["ub"] if have_utt else None, p["fol"], p["cp"], p["state"] if want_state else None,
+                p["seg"][0] if have_utt else None, p["seg"][1] if have_utt else None, p["seg"][2] if have_utt else None,
+                p["t_end"], p["status"])
+        pU = p["Un"] if have_utt else None
+        byref = ctypes.byref(params)
+        if S > 1:
+            rc = self._lib.ctcfa_align_batch_spans(self._h, byref, B, V, S, p["Tn"], p["Cn"], pU, lpz_arg, *tail)
             self._check(rc, "ctcfa_align_batch_spans")
         elif emission_of is not None:
-            rc = self._lib.ctcfa_align_batch_shared(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
-                                                    _i32p(emission_of),
-                                                    _ptr(lpz) if d_lpz is None else ctypes.c_void_p(int(d_lpz)),
+            rc = self._lib.ctcfa_align_batch_shared(self._h, byref, B, V, p["Tn"], p["Cn"], pU, p["em"], lpz_arg,
                                                     0 if d_lpz is None else 1, *tail,
                                                     ctypes.c_void_p(stream) if stream else None)
             self._check(rc, "ctcfa_align_batch_shared")
         elif d_lpz is None:
-            rc = self._lib.ctcfa_align_batch(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
-                                             _ptr(lpz), *tail)
+            rc = self._lib.ctcfa_align_batch(self._h, byref, B, V, p["Tn"], p["Cn"], pU, lpz_arg, *tail)
             self._check(rc, "ctcfa_align_batch")
         else:
-            rc = self._lib.ctcfa_align_batch_resident(self._h, ctypes.byref(params), B, V, _i32p(T), _i32p(C), _i32p(U),
-                                                      ctypes.c_void_p(int(d_lpz)), *tail,
+            rc = self._lib.ctcfa_align_batch_resident(self._h, byref, B, V, p["Tn"], p["Cn"], pU, lpz_arg, *tail,
                                                       ctypes.c_void_p(stream) if stream else None)
             self._check(rc, "ctcfa_align_batch_resident")
-        t_off = np.concatenate([[0], np.cumsum(T)])
-        c_off = np.concatenate([[0], np.cumsum(C)])
-        u_off = np.concatenate([[0], np.cumsum(U)]) if have_utt else None
+        fol, cp, state, seg = st["fol"], st["cp"], st["state"], st["seg"]
+        status, t_end = st["status"][:B].tolist(), st["t_end"][:B].tolist()
         out = []
+        t0 = c0 = u0 = 0
         for b in range(B):
-            d = dict(status=int(status[b]), t_end=int(t_end[b]),
-                     frame_of_label=fol[c_off[b]:c_off[b + 1]], char_prob=cp[t_off[b]:t_off[b + 1]])
+            t1, c1 = t0 + Ts[b], c0 + Cs[b]
+            d = dict(status=status[b], t_end=t_end[b], frame_of_label=fol[c0:c1].copy(), char_prob=cp[t0:t1].copy())
             if want_state:
-                d["state"] = state[t_off[b]:t_off[b + 1]]
+                d["state"] = state[t0:t1].copy()
             if have_utt:
-                d["seg_start"] = seg[0][u_off[b]:u_off[b + 1]]
-                d["seg_end"] = seg[1][u_off[b]:u_off[b + 1]]
-                d["seg_score"] = seg[2][u_off[b]:u_off[b + 1]]
+                u1 = u0 + Us[b]
+                d["seg_start"] = seg[0, u0:u1].copy()
+                d["seg_end"] = seg[1, u0:u1].copy()
+                d["seg_score"] = seg[2, u0:u1].copy()
+                u0 = u1
+            t0, c0 = t1, c1
             out.append(d)
         return out
 
@@ -324,6 +368,22 @@ class Plan:
         fn = self._lib.ctcfa_plan_run_pipelined if pipelined else self._lib.ctcfa_plan_run_device
         rc = fn(self._h, *[ctypes.c_void_p(a) if a else None for a in args])
         self._eng._check(rc, "ctcfa_plan_run_pipelined" if pipelined else "ctcfa_plan_run_device")
+
+    def bind(self, d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start, d_seg_end,
+             d_seg_score, d_t_end, d_status, stream=None, pipelined=False):
+        """``run_device`` with these arguments as a closure: the ctypes conversions are done once, not on
+        every call (a dozen ``c_void_p`` objects cost as much as launching a small kernel)."""
+        args = tuple(ctypes.c_void_p(a) if a else None for a in
+                     (d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start, d_seg_end, d_seg_score,
+                      d_t_end, d_status, stream))
+        fn = self._lib.ctcfa_plan_run_pipelined if pipelined else self._lib.ctcfa_plan_run_device
+        h, check, what = self._h, self._eng._check, "ctcfa_plan_run_pipelined" if pipelined else "ctcfa_plan_run_device"
+
+        def run():
+            rc = fn(h, *args)
+            if rc:
+                check(rc, what)
+        return run
 
     def flush(self, stream=None):
         """Make ``stream`` wait for every backtrack a pipelined run left outstanding."""

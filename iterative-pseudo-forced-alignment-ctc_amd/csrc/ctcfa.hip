@@ -6,6 +6,7 @@
 #include "ctcfa_kernels.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,8 @@ struct ctcfa_engine {
     size_t h_in_cap = 0;
     unsigned char* h_out = nullptr;
     size_t h_out_cap = 0;
+    int64_t trace_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // CTCFA_CALL_TRACE
+    int64_t trace_calls = 0;
 };
 
 struct ctcfa_plan {
@@ -369,6 +372,12 @@ int ctcfa_engine_create(ctcfa_engine** out, int device) {
 
 void ctcfa_engine_destroy(ctcfa_engine* eng) {
     if (!eng) return;
+    if (eng->trace_calls) {
+        const char* names[7] = {"plan", "pack", "enqueue uploads", "launch kernels", "enqueue download", "wait", "unpack"};
+        std::fprintf(stderr, "ctcfa call trace, %lld calls, us per call:", (long long)eng->trace_calls);
+        for (int k = 0; k < 7; ++k) std::fprintf(stderr, "  %s %.1f", names[k], eng->trace_ns[k] / 1e3 / (double)eng->trace_calls);
+        std::fprintf(stderr, "\n");
+    }
     for (auto& sl : eng->scratch)
         if (sl.p) (void)hipFree(sl.p);
     if (eng->h_in) (void)hipHostFree(eng->h_in);
@@ -1074,10 +1083,21 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
                int32_t* state, double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
                int32_t* status) {
     DeviceGuard on_device(eng->device);
+    // CTCFA_CALL_TRACE=1 (tuning): where the host time of a call goes, printed when the engine is destroyed
+    static const bool trace = std::getenv("CTCFA_CALL_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto tp = now();
+    auto lap = [&](int k) {
+        if (!trace) return;
+        const auto t = now();
+        eng->trace_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(t - tp).count();
+        tp = t;
+    };
     ctcfa_plan* pl = nullptr;
     int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of,
                               label_width > 1 ? nullptr : labels, label_width);
     if (rc != CTCFA_OK) return rc;
+    lap(0);
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
     const size_t n_lpz = (size_t)pl->total_lpz_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
     const size_t n_utt = (size_t)pl->total_U, n_ub = n_utt + batch;
@@ -1116,8 +1136,10 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     std::memcpy(h + in_lab, labels, n_lab * 4 * (size_t)pl->S);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
     if (n_watch) std::memcpy(h + in_watch, pl->watch.data(), n_watch * sizeof(ctcfa::WatchDesc));
+    lap(1);
     AB_TRY(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, st));
     if (host_lpz) AB_TRY(hipMemcpyAsync(d_lpz, host_lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
+    lap(2);
     pl->d_roles = reinterpret_cast<ctcfa::FillRoles*>(d_in + in_roles);
     pl->d_segs = reinterpret_cast<SegDesc*>(d_in + in_segs);
     pl->d_watch = n_watch ? reinterpret_cast<ctcfa::WatchDesc*>(d_in + in_watch) : nullptr;
@@ -1133,9 +1155,12 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
         cleanup();
         return rc;
     }
+    lap(3);
     unsigned char* ho = eng->h_out;
     AB_TRY(hipMemcpyAsync(ho, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    lap(4);
     AB_TRY(hipStreamSynchronize(st));
+    lap(5);
     std::memcpy(frame_of_label, ho + o_fol, n_lab * 4);
     std::memcpy(char_prob, ho + o_cp, n_frm * 4);
     if (state) std::memcpy(state, ho + o_state, n_frm * 4);
@@ -1148,6 +1173,8 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     }
 #undef AB_TRY
     ctcfa_plan_destroy(pl);
+    lap(6);
+    if (trace) ++eng->trace_calls;
     return CTCFA_OK;
 }
 

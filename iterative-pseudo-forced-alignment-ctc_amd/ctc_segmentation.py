@@ -79,11 +79,14 @@ class CtcSegmentationParameters:
         flags = self.flags
         if self.backtrack_from_max_t:
             flags |= _native.FLAG_BACKTRACK_FROM_MAX_T
-        return _native.default_params(
-            blank=int(self.blank), flags=flags, min_window_size=int(self.min_window_size),
-            max_window_size=int(self.max_window_size),
-            score_min_mean_over_L=int(self.score_min_mean_over_L),
-            index_duration=float(self.index_duration_in_seconds))
+        key = (int(self.blank), flags, int(self.min_window_size), int(self.max_window_size),
+               int(self.score_min_mean_over_L), float(self.index_duration_in_seconds))
+        cached = self.__dict__.get("_native_params")
+        if cached is None or cached[0] != key:   # (one struct per parameter set, not per call)
+            cached = (key, _native.default_params(blank=key[0], flags=key[1], min_window_size=key[2], max_window_size=key[3],
+                                                  score_min_mean_over_L=key[4], index_duration=key[5]))
+            self.__dict__["_native_params"] = cached
+        return cached[1]
 
 
 def prepare_token_list(config, text):
@@ -234,18 +237,18 @@ def _validate_segments(lpz_list, labels, utt_begin_list):
             raise ValueError(f"segment {b}: emissions must be [T, {V}] like the first segment's, got {tuple(l.shape)}")
         if len(g) < 2 or g[0] != -1:
             raise ValueError(f"segment {b}: ground truth must start with -1 and hold at least one more label")
-        body = g[1:]
-        if body.size and (int(body.min()) < 0 or int(body.max()) >= V):
+        # (one pass: as unsigned numbers, negative ids are far above any vocabulary)
+        if int(g[1:].view(np.uint32).max()) >= V:
             raise IndexError(f"segment {b}: label id outside the vocabulary [0, {V})")
     if utt_begin_list is not None:
         for b, (u, g) in enumerate(zip(utt_begin_list, labels)):
-            u = np.asarray(u)
-            C = len(g)
-            if u.ndim != 1 or len(u) < 1:
+            if getattr(u, "ndim", 1) != 1 or len(u) < 1:
                 raise ValueError(f"segment {b}: utt_begin_indices must hold U + 1 indices")
+            ul = u.tolist() if hasattr(u, "tolist") else list(u)
+            C = len(g)
             # determine_utterance_segments reads timings[i-1], timings[i], timings[i+1] for every start i
             # and timings[e-1], timings[e] for the closing index e
-            if len(u) > 1 and (int(u[:-1].min()) < 1 or int(u[:-1].max()) > C - 2 or int(u[-1]) < 1 or int(u[-1]) > C - 1):
+            if len(ul) > 1 and (min(ul[:-1]) < 1 or max(ul[:-1]) > C - 2 or ul[-1] < 1 or ul[-1] > C - 1):
                 raise IndexError(f"segment {b}: utterance start outside the label sequence (C = {C})")
 
 
