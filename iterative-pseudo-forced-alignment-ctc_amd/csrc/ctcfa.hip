@@ -82,6 +82,7 @@ struct ctcfa_plan {
     int nwatch_max = 0;
     int S = 1;                        // label width (> 1: multi-character tokens, every segment through windowed_kernel)
     int n_fill = 0;                   // segments that get a fill workgroup of their own
+    int n_emission_blocks = 0;
     int64_t total_lpz_T = 0;
     // windowed regime (T > min_window_size): segment indices, fp32 table + per-column offsets
     std::vector<int32_t> win_list;
@@ -754,6 +755,24 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "segment too long for the backtrack record buffer");
     }
+    pl->n_emission_blocks = 0;
+    for (int b = 0; b < batch; ++b) pl->n_emission_blocks += (!emission_of || emission_of[b] == b);
+    // Workgroup b of both kernels takes table entry b: longest first.  A ragged batch larger than what the
+    // chip holds at once then ends with its short segments (no long one left over for the tail), and in a
+    // batch that is resident at once the long segments spread over the CUs before the short ones join
+    // them.  Everything a kernel needs is inside the entry (seg_index = the caller's position).
+    if (batch > 1 && !std::getenv("CTCFA_NO_SORT")) {
+        std::vector<int32_t> pos(batch);
+        std::vector<SegDesc> sorted(pl->segs);
+        std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& a, const SegDesc& b) {
+            const int64_t ca = (a.prestatus == CTCFA_ST_OK) ? (int64_t)a.T * (a.fill_skip ? 1 : a.C) : 0;
+            const int64_t cb = (b.prestatus == CTCFA_ST_OK) ? (int64_t)b.T * (b.fill_skip ? 1 : b.C) : 0;
+            return ca > cb;
+        });
+        for (int i = 0; i < batch; ++i) pos[sorted[i].seg_index] = i;
+        for (auto& w : pl->win_list) w = pos[w];   // (windowed_kernel indexes the table through this list)
+        pl->segs.swap(sorted);
+    }
 
 #define PLAN_TRY(expr)                                                                        \
     do {                                                                                      \
@@ -1243,16 +1262,7 @@ int ctcfa_plan_get_sharing(const ctcfa_plan* pl, int32_t* n_fills, int32_t* n_em
         for (const SegDesc& s : pl->segs) n += (s.prestatus == CTCFA_ST_OK && !s.fill_skip);
         *n_fills = n;
     }
-    if (n_emission_blocks) {
-        int n = 0;
-        int64_t last = -1;
-        for (const SegDesc& s : pl->segs)
-            if (s.lpz_off > last || last < 0) {
-                ++n;
-                last = s.lpz_off;
-            }
-        *n_emission_blocks = n;
-    }
+    if (n_emission_blocks) *n_emission_blocks = pl->n_emission_blocks;
     return CTCFA_OK;
 }
 

@@ -125,8 +125,17 @@ struct FillRoles {
 
 constexpr int kHaloRows = 16;       // rows between two refreshes of a tile's halo (a "group")
 constexpr int kGroups = kRows / kHaloRows;
-constexpr int kPollLead = 4;        // a tile asks for its neighbour's group this many rows before it needs it
-constexpr int kPeekLead = 3;        // ... and reads the counter this many rows before it looks at the value
+#ifndef CTCFA_POLL_LEAD
+#define CTCFA_POLL_LEAD 4
+#endif
+#ifndef CTCFA_PEEK_LEAD
+#define CTCFA_PEEK_LEAD 3
+#endif
+#ifndef CTCFA_NBR_SLEEP
+#define CTCFA_NBR_SLEEP 1
+#endif
+constexpr int kPollLead = CTCFA_POLL_LEAD;   // a tile asks for its neighbour's group this many rows before it needs it
+constexpr int kPeekLead = CTCFA_PEEK_LEAD;   // ... and reads the counter this many rows before it looks at the value
 constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, pad
 constexpr int kBigCount = 0x3fffffff;
 constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a lost counter must not hang the GPU
@@ -807,7 +816,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         CTCFA_STAMP_BEGIN();
                         int f, spins = 0;
                         do {
-                            __builtin_amdgcn_s_sleep(1);
+#if CTCFA_NBR_SLEEP > 0
+                            __builtin_amdgcn_s_sleep(CTCFA_NBR_SLEEP);
+#endif
                             f = __builtin_amdgcn_readfirstlane(flags[w - 1]);
                             if (++spins > kSpinCap) { CTCFA_SPIN_DIAG("tile-nbr", w, g, f); break; }
                         } while (f < g + 1);

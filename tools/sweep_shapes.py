@@ -80,6 +80,12 @@ for s in range(512):
     U = max(1, T // 140)
     rag.append(syn.make_segment(5000 + s % 32, T, 32, U, 24))
 run("ragged T~U[150,3500]", rag)
+rag4 = []
+for s in range(2048):
+    T = int(rng.integers(150, 3500))
+    U = max(1, T // 140)
+    rag4.append(syn.make_segment(5000 + s % 32, T, 32, U, 24))
+run("ragged T~U[150,3500], 2048 segments", rag4)
 words = []
 for s in range(4096):
     T = int(rng.integers(100, 750))
