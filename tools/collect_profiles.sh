@@ -10,6 +10,8 @@ tools/collect_traffic.sh > $OUT/traffic.log 2>&1 && cp gpurun_out/pmc_traffic.js
 && timeout -k 10 300 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err \
 && timeout -k 10 300 python bench.py --serial > $OUT/${R}_bench_serial.json 2>> $OUT/bench.err \
 && timeout -k 10 300 python bench.py --workload replay > $OUT/${R}_bench_replay.json 2>> $OUT/bench.err \
+&& timeout -k 10 300 python bench.py --workload replay --speculate 1 > $OUT/${R}_bench_replay_speculate1.json 2>> $OUT/bench.err \
+&& timeout -k 10 300 python bench.py --workload replay --speculate 2 > $OUT/${R}_bench_replay_speculate2.json 2>> $OUT/bench.err \
 && timeout -k 10 300 python bench.py --workload words > $OUT/${R}_bench_words.json 2>> $OUT/bench.err \
 && timeout -k 10 300 python bench.py --workload corpus > $OUT/${R}_bench_corpus.json 2>> $OUT/bench.err \
 && rm -rf gpurun_out/kstats && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -- python3 bench.py --steps 4000 --cpu-sample 0 > $OUT/kstats_bench.json 2> $OUT/kstats.err \
@@ -21,5 +23,8 @@ tools/collect_traffic.sh > $OUT/traffic.log 2>&1 && cp gpurun_out/pmc_traffic.js
 && timeout -k 10 300 python tools/vocab_sweep.py 2>/dev/null | grep "V=" > $OUT/${R}_vocab.txt \
 && timeout -k 10 300 python tools/call_latency.py 2>/dev/null | grep "T=" > $OUT/${R}_call_latency.txt \
 && timeout -k 10 300 python tools/windowed_timing.py 2>/dev/null | grep "T=" > $OUT/${R}_windowed.txt \
-&& (timeout -k 10 120 ./tools/row_rate) > $OUT/${R}_row_rate.txt 2>&1
+&& (timeout -k 10 120 ./tools/row_rate) > $OUT/${R}_row_rate.txt 2>&1 \
+&& timeout -k 10 200 python tools/call_trace.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_call_trace.txt \
+&& timeout -k 10 200 python tools/small_modes.py 2>/dev/null | grep "T=" > $OUT/${R}_small_window_modes.txt \
+&& tools/fill_cycles.sh > $OUT/${R}_fill_cycles.txt 2>&1
 echo "collect_profiles exit $?"
