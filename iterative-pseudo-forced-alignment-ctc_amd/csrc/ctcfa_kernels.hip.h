@@ -341,7 +341,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const bool valid = t < T;
                 notneg |= !(e[q] <= 0.0f);
                 float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
-                if (sv < V) row[sv] = valid ? make_float2(e[q], (gratis && sv == blank) ? 0.0f : max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
+                float mq = max3f(lb, e[q], kProbMax);
+                if (gratis) mq = (sv == blank) ? 0.0f : mq;   // (uniform branch: nothing in the way when the flag is off)
+                if (sv < V) row[sv] = valid ? make_float2(e[q], mq) : make_float2(0.f, 0.f);
                 if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
                     row[VP] = make_float2(-__builtin_inff(),
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
@@ -458,7 +460,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), blank));
                         const bool valid = (t0 + i * PARTS) < T;  // uniform
                         notneg |= !(e[i] <= 0.0f);
-                        float2 v = make_float2(e[i], (gratis && svl == blank) ? 0.0f : max3f(lb, e[i], kProbMax));
+                        float2 v = make_float2(e[i], max3f(lb, e[i], kProbMax));
+                        if (gratis) v.y = (svl == blank) ? 0.0f : v.y;   // (uniform branch)
                         if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
                         *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
@@ -492,6 +495,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     }
                 }
             };
+            // (Tried in round 2 and dropped: dwordx2 loads with two or three rows per pass for even vocabularies --
+            // fewer passes, but lane-varying row addresses and store targets; V = 38: 183 us against 166.)
             run(std::integral_constant<int, 2>{});   // (the plan always gives this path two producers)
         } else if constexpr (PASSES == CH) {
             // whole block in one chunk (VP == 32, V < 32).  One register set: the loads of block jb+1 are
@@ -541,8 +546,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                              : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1[r]), blank & 63));
                         const bool valid = (t0 + r * PARTS) < T;  // uniform
                         notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
-                        float2 v0 = make_float2(e0[r], (gratis && lane == blank) ? 0.0f : max3f(lb, e0[r], kProbMax));
-                        float2 v1 = make_float2(e1[r], (gratis && lane + 64 == blank) ? 0.0f : max3f(lb, e1[r], kProbMax));
+                        float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
+                        float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
+                        if (gratis) {   // (uniform branch; the plan refuses the flag for these vocabularies anyway)
+                            v0.y = (lane == blank) ? 0.0f : v0.y;
+                            v1.y = (lane + 64 == blank) ? 0.0f : v1.y;
+                        }
                         float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         if (!valid) {
                             v0 = make_float2(0.f, 0.f);
