@@ -1,0 +1,21 @@
+#!/bin/bash
+# Tuning builds of libctcfa_hip.so from the current sources with extra -D macros (one vocabulary pitch:
+# compiles in ~25 s).  Load one with CTCFA_LIB=$PWD/variants/<name>.so.
+#   tools/build_variant.sh stamp3 -DCTCFA_STAMP=3        per-tile cycle stamps (tools/stamps2.py)
+#   tools/build_variant.sh abl2 -DCTCFA_ABL=2            group hand-over partly left out (WRONG results, timing only)
+#   tools/build_variant.sh prio1 -DCTCFA_TILE_PRIO=1     tile priorities; also CTCFA_PRODUCER_PRIO, CTCFA_PF,
+#                                                        CTCFA_POLL_LEAD, CTCFA_PEEK_LEAD, CTCFA_NBR_SLEEP, CTCFA_VGPR_CAP,
+#                                                        CTCFA_NO_DEADZONE, CTCFA_DEBUG_SPIN, CTCFA_CK_DEPTH
+#   tools/build_variant.sh all                           stamp3 + abl0..4 (what tools/fill_cycles.sh needs)
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p variants
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize -DCTCFA_DEV_VP32_ONLY"
+S=iterative-pseudo-forced-alignment-ctc_amd/csrc/ctcfa.hip
+if [ "$1" = all ]; then
+  /opt/rocm/bin/hipcc $F -DCTCFA_STAMP=3 $S -o variants/stamp3.so
+  for L in 0 1 2 3 4; do /opt/rocm/bin/hipcc $F -DCTCFA_ABL=$L $S -o variants/abl$L.so; done
+else
+  n=$1; shift
+  /opt/rocm/bin/hipcc $F "$@" $S -o variants/$n.so
+fi

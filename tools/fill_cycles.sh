@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where the fill kernel's cycles go.  Needs the tuning builds variants/stamp3.so
 # (-DCTCFA_STAMP=3) and variants/abl0..4.so (-DCTCFA_ABL=n: parts of the group hand-over left out, results
-# WRONG, timing only), built from the current sources with -DCTCFA_DEV_VP32_ONLY.
+# WRONG, timing only), built from the current sources by tools/build_variant.sh all.
 echo "## s_memtime stamps: per-tile totals and cycles per 8 rows of block 40 (config 3; then 128 segments)"
 for a in "2" "2 128 3000 22 28"; do
   echo "== tools/stamps2.py $a"
