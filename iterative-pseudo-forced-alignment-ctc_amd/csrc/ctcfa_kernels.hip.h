@@ -98,7 +98,10 @@ struct WatchDesc {     // one watched label column of a shared fill, ascending p
     int32_t reserved;
 };
 constexpr int kMaxWatch = 16;        // watch columns per shared fill (more members: fills of their own)
-constexpr int kWatchMaxK = 2;        // widest tile the watch variant of the row loop is compiled for (wider ones are at their VGPR cap)
+#ifndef CTCFA_WATCH_MAX_K
+#define CTCFA_WATCH_MAX_K 2
+#endif
+constexpr int kWatchMaxK = CTCFA_WATCH_MAX_K;        // widest tile the watch variant of the row loop is compiled for (wider ones are at their VGPR cap)
 
 // Launch shape of the fill kernel: what each wave of a workgroup does.  Tiles are numbered left
 // to right; a tile is one wave, lane l owns K consecutive padded columns.  The first HL lanes of a
@@ -296,6 +299,16 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #endif
         };
         auto publish = [&](int jb) {
+            // blank_transition_cost_zero: the blank entry's stay step of the rows this wave just staged becomes 0
+            // (one store per block, after the rows' own stores -- LDS executes a wave's operations in order; nothing
+            // in the per-row code, so nothing in the way when the flag is off)
+            if (gratis) {
+                const int nmine = roles->nprod == 2 ? kRows / 2 : kRows;
+                const int row = roles->nprod == 2 ? part + 2 * lane : lane;
+                if (lane < nmine)
+                    *reinterpret_cast<float*>(smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) +
+                                              static_cast<uint32_t>(row * (PITCH * 8) + blank * 8 + 4)) = 0.0f;
+            }
             if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
             asm volatile("" ::: "memory");  // data and posflag first, then the counter (LDS executes a wave's operations in order)
             if (lane == 0) flags[16 + part] = jb + 1;
@@ -341,9 +354,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const bool valid = t < T;
                 notneg |= !(e[q] <= 0.0f);
                 float2* row = reinterpret_cast<float2*>(slot + r * (PITCH * 8));
-                float mq = max3f(lb, e[q], kProbMax);
-                if (gratis) mq = (sv == blank) ? 0.0f : mq;   // (uniform branch: nothing in the way when the flag is off)
-                if (sv < V) row[sv] = valid ? make_float2(e[q], mq) : make_float2(0.f, 0.f);
+                if (sv < V) row[sv] = valid ? make_float2(e[q], max3f(lb, e[q], kProbMax)) : make_float2(0.f, 0.f);
                 if (sv == 0)  // start-column pseudo entry: e = -inf, m = table[t,0]'s stay step
                     row[VP] = make_float2(-__builtin_inff(),
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
@@ -384,12 +395,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const bool valid = (t0 + p * RPP) < T;
                     float4 lo = make_float4(v.x, max3f(lb, v.x, kProbMax), v.y, max3f(lb, v.y, kProbMax));
                     float4 hi = make_float4(v.z, max3f(lb, v.z, kProbMax), v.w, max3f(lb, v.w, kProbMax));
-                    if (gratis && lv == (blank & ~3)) {   // this lane holds the blank entry
-                        if (blank_comp == 0) lo.y = 0.0f;
-                        else if (blank_comp == 1) lo.w = 0.0f;
-                        else if (blank_comp == 2) hi.y = 0.0f;
-                        else hi.w = 0.0f;
-                    }
                     if (!valid) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
                     const float2 sp = make_float2(-__builtin_inff(),
                                                   (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
@@ -461,7 +466,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         const bool valid = (t0 + i * PARTS) < T;  // uniform
                         notneg |= !(e[i] <= 0.0f);
                         float2 v = make_float2(e[i], max3f(lb, e[i], kProbMax));
-                        if (gratis) v.y = (svl == blank) ? 0.0f : v.y;   // (uniform branch)
                         if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
                         *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
@@ -548,10 +552,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
                         float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
                         float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
-                        if (gratis) {   // (uniform branch; the plan refuses the flag for these vocabularies anyway)
-                            v0.y = (lane == blank) ? 0.0f : v0.y;
-                            v1.y = (lane + 64 == blank) ? 0.0f : v1.y;
-                        }
                         float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                         if (!valid) {
                             v0 = make_float2(0.f, 0.f);
@@ -1529,7 +1529,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         const float e1 = lab < 0 ? -__builtin_inff() : ee[i];
                         const float m = lab < 0 ? (preamble ? 0.0f : __builtin_fmaxf(lb[i], kProbMax))
                                                 : max3f(lb[i], ee[i], kProbMax);
-                        cell(prev, dec, e1, m, (gratis && lab == p.blank) ? 0.0f : m);
+                        cell(prev, dec, e1, m, (gratis && lab == p.blank) ? 0.0f : m);   // (slow path: the select stays)
                     }
                     return c <= 0 ? 0u : dec;  // start column and left of it: STAY
                 };
@@ -1594,8 +1594,14 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         lds_barrier();                          // B (waits for the reads above)
                         if (j >= 1) {
                             uint32_t dec = 0u;
+                            if (!gratis) {   // (uniform: no select per row when the flag is off)
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y, (gratis && lab == p.blank) ? 0.0f : emr[i].y);
+                                for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y, emr[i].y);
+                            } else {
+                                const bool free_stay = lab == p.blank;
+#pragma unroll
+                                for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y, free_stay ? 0.0f : emr[i].y);
+                            }
                             wbuf[lane] = c <= 0 ? 0u : dec;
                         }
                         --j;
