@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="synthetic", choices=["synthetic", "replay", "words", "corpus"])
     ap.add_argument("--files", type=int, default=64, help="replay: audio files advanced in lockstep per GPU")
+    ap.add_argument("--copy-results", action="store_true",
+                    help="replay: the scores go to HBM and come back with a copy per round (default: the backtrack kernel "
+                         "writes them straight into pinned host memory, which is all the state machine reads)")
     ap.add_argument("--speculate", type=int, default=0,
                     help="replay: every DP request also carries the n texts the repeat loop may ask for next (the window "
                          "minus its last 1..n utterances) -- shared emissions and trellis fill, foreseen requests cost no round")
@@ -207,8 +210,11 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
         d_lab = torch.from_numpy(np.concatenate([s[1] for s in g]).astype(np.int32)).to(dev)
         d_ub = torch.from_numpy(np.concatenate([s[2] for s in g]).astype(np.int32)).to(dev)
         nT, nC, nU, B = sum(Ts), sum(Cs), max(1, sum(Us)), len(g)
+        direct = sequential and not args.copy_results   # scores written by the kernel into pinned host memory
         outs = [dict(fol=torch.empty(nC, dtype=torch.int32, device=dev), cp=torch.empty(nT, dtype=torch.float32, device=dev),
-                     seg=torch.empty(3, nU, dtype=torch.float64, device=dev), te=torch.empty(B, dtype=torch.int32, device=dev),
+                     seg=(torch.zeros(3, nU, dtype=torch.float64).pin_memory() if direct
+                          else torch.empty(3, nU, dtype=torch.float64, device=dev)),
+                     te=torch.empty(B, dtype=torch.int32, device=dev),
                      status=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(3)]
         G.append(dict(plan=plan, lpz=d_lpz, lab=d_lab, ub=d_ub, outs=outs, frames=nT, segs=g, n=0,
                       host=torch.empty(3, nU, dtype=torch.float64).pin_memory() if sequential else None))
@@ -226,7 +232,8 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
         g["run"][g["n"] % 3]()
         g["n"] += 1
         if sequential:   # the state machine reads this round's scores before it can form the next window
-            g["host"].copy_(o["seg"], non_blocking=True)
+            if args.copy_results:
+                g["host"].copy_(o["seg"], non_blocking=True)
             stream.synchronize()
 
     def step():
@@ -321,8 +328,10 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
                        "fills_per_step_this_gpu": n_fills,
                        "frames_per_step_this_gpu": frames_step, "vocab": V, "tile_shapes_K_W": shapes,
                        "parallelism": f"unit-sharded x{world}", "parity": parity,
-                       "schedule": ("one launch at a time + host read-back of the scores after every round (the anchor "
-                                    "state machine needs them)" if sequential else
+                       "schedule": (("one launch at a time; the scores of every round are on the host before the next one starts (the "
+                                     "anchor state machine needs them): " +
+                                     ("copied back from HBM" if args.copy_results else "written by the backtrack kernel into pinned host memory"))
+                                    if sequential else
                                     ("serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"))},
             "roofline": roofline_entry(fill_ms, bt_ms, dt / args.steps * 1e3, stride, fill_bytes, step_bytes, False),
             "cpu_baseline": cpu,
