@@ -1,6 +1,6 @@
 // ctcfa_kernels.hip.h -- gfx950 device code of the CTC forced-alignment engine.
 //
-// What is computed (per segment, S = 1 labels):
+// What is computed (per segment; single labels, S = 1, unless said otherwise):
 //   table[t,c] = max( table[t-1,c-1] + lpz[t,g_c],  table[t-1,c] + max(lpz[t,blank], lpz[t,g_c]),  -1e9 )
 // in fp32, exactly the recurrence of ctc-segmentation 1.7.1's cython_fill_table
 // (requirements.txt:13; reached from src/iterative_utterance_alignment.py:216), plus the
@@ -13,30 +13,37 @@
 // the path.  Either way the fp32 trellis itself never leaves the chip.
 //
 // Kernels:
-//   fill_kernel<KH,KL,VP,CK>  T <= min_window_size, vocabulary <= 128: the hot one
+//   fill_kernel<K,VP,CK>      T <= min_window_size, vocabulary <= 128: the hot one
 //   fill_gather_kernel        same, vocabulary > 128 (no LDS staging of vocabulary rows)
 //   backtrack_kernel<PB>      end cell, walk (over decision words, or recomputing them from the
 //                             checkpoint rows), per-frame outputs, scores
-//   windowed_kernel           T > min_window_size: the package's windowed regime, literally
+//   windowed_kernel           T > min_window_size: the package's windowed regime, literally; also
+//                             every segment with a label matrix (multi-character tokens, S > 1)
 //
 // Mapping of fill_kernel (CDNA4, 64-wide waves, no MFMA: a max-plus scan is not a contraction):
-//   * one workgroup per segment; its padded columns are cut into tiles, a compute wave owns
-//     one tile, lane l owns K consecutive columns -> the c-1 neighbour is in-lane for k>0 and
-//     one DPP wave_shr:1 for k==0; lane 0 takes the previous tile's last column from an LDS
-//     ring.  A role table (FillRoles) says what each wave of the workgroup is: heavy tile,
-//     light tile, producer, idle;
-//   * time runs in blocks of R=32 rows; stage l works on block (s - l) in step s (a skewed
-//     pipeline, one s_barrier per step) so that the cross-tile dependency is a block old;
-//   * emission rows are staged once per workgroup through an LDS ring as (e, m) pairs,
-//     m = max(lb, e, -1e9), row pitch VP+2 entries; a gather is one ds_read_b64; entry VP is
-//     the "start column" pseudo-label (e = -inf, m = 0) that makes column 0
-//     (ground_truth == -1) and the left padding reproduce table[t,0];
-//   * decisions are shifted into a per-(lane,k) register (v_alignbit) and stored every
-//     32 rows as words bits[block][column] (checkpoint mode: the table value of the block's last
-//     row goes there instead); HBM traffic per segment is
-//     4*T*V (emissions, once) + T*Cpad/8 (bits) + 4*T (last-column scores);
-//   * blocks that cannot matter are skipped exactly (dead zone behind the end cell's cone;
-//     the -1e9 zone above the diagonal while every emission so far is <= 0).
+//   * one workgroup per segment; its padded columns are cut into tiles, a compute wave owns one
+//     tile, lane l owns K consecutive columns -> the c-1 neighbour is in-lane for k>0 and one DPP
+//     wave_shr:1 (folded into the add) for k==0.  The first HL lanes of a tile are its HALO: copies
+//     of the left neighbour's last HL*K >= 16 columns, which go wrong one column per row and are
+//     refreshed every 16 rows (a "group") from an LDS exchange ring -- no per-row traffic between
+//     tiles and no pipeline skew.  A role table (FillRoles) says what each wave is: tile, producer
+//     (1 or 2), idle padding;
+//   * no workgroup barrier after start-up: waves pace each other through counters in LDS (done[w],
+//     staged[p]); every wait is bounded (a lost counter becomes status 5, never a hang);
+//   * emission rows are staged once per workgroup through an LDS ring of 32-row blocks as (e, m)
+//     pairs, m = max(lb, e, -1e9), row pitch VP+2 entries; a gather is one ds_read_b64; entry VP is
+//     the "start column" pseudo-label (e = -inf, m = 0) that makes column 0 (ground_truth == -1) and
+//     the left padding reproduce table[t,0]; blank_transition_cost_zero = the blank entry's m is 0;
+//   * decisions are shifted into a per-(lane,k) register (v_alignbit) and stored every 32 rows as
+//     words bits[block][column] (checkpoint mode: the table value of the block's last row goes there
+//     instead); HBM traffic per segment is 4*T*V (emissions, once) + T*Cpad/8 (trace words) + 4*T
+//     (last-column scores);
+//   * the tile that holds the last label column publishes its score every row (for the end cell's
+//     argmax); a SHARED fill (texts that are prefixes of one another over the same emissions) does
+//     the same for every member's last column ("watch columns");
+//   * blocks that cannot matter are skipped exactly (dead zone behind the end cell's cone -- per
+//     tile against the nearest watch column; the -1e9 zone above the diagonal while every emission
+//     so far is <= 0).
 #pragma once
 #include <hip/hip_runtime.h>
 #ifndef CTCFA_PRODUCER_PRIO

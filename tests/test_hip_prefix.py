@@ -250,3 +250,31 @@ def test_speculating_anchor_iteration_equals_the_plain_one(pkg, oracle):
     assert run_replay(1, r1) == full
     assert r1["requests"] == r0["requests"] and r1["launches"] + r1["answered_ahead"] == r0["launches"]
     assert r1["answered_ahead"] >= 10
+
+
+def test_shared_fills_at_size_equal_separate_fills(pkg, oracle):
+    """Groups at the sizes of BASELINE configs[2] (T = 3000, up to ~1500 label columns, up to 15 tiles):
+    the shared call must give, member by member, exactly what separate emissions give (HIP against HIP, every
+    member), and a sample of members is checked against the oracle."""
+    syn = pkg.synthetic
+    rng = np.random.default_rng(2024)
+    shared, separate = [], []
+    for g in range(24):
+        T = int(rng.integers(800, 3001))
+        U = int(rng.integers(2, 40))
+        n = int(rng.integers(8, max(9, min(40, (T - 3) // (U + 1) - 1))))
+        seg = syn.make_segment(4000 + g, T, 32, U, n)
+        keep = sorted(set(int(k) for k in rng.integers(1, U + 1, size=int(rng.integers(1, 7)))) | {U}, reverse=True)
+        members = prefixes(seg, keep=keep)
+        shared += members
+        separate += [(m[0].copy(), m[1], m[2]) for m in members]    # own emission arrays: nothing shared
+    assert max(len(s[1]) for s in shared) > 1000
+    a = run(pkg, shared)
+    b = run(pkg, separate)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x["status"] == y["status"] == 0, i
+        assert x["t_end"] == y["t_end"], i
+        for k in ("frame_of_label", "char_prob", "state", "seg_start", "seg_end", "seg_score"):
+            assert np.array_equal(x[k], y[k]), (i, k)
+    sample = list(range(0, len(shared), 7))
+    check(oracle, [shared[i] for i in sample], [a[i] for i in sample])
