@@ -278,3 +278,23 @@ def test_shared_fills_at_size_equal_separate_fills(pkg, oracle):
             assert np.array_equal(x[k], y[k]), (i, k)
     sample = list(range(0, len(shared), 7))
     check(oracle, [shared[i] for i in sample], [a[i] for i in sample])
+
+
+def test_bad_sharing_arguments_are_refused(pkg, engine):
+    syn = pkg.synthetic
+    lpz, gt, ub = syn.make_segment(1, 200, 32, 3, 10)
+    config = pkg.CtcSegmentationParameters(index_duration=DUR).to_native()
+    lab = [gt.astype(np.int32), gt[:ub[2] + 1].astype(np.int32)]
+    ubs = [ub, ub[:3]]
+    with pytest.raises(ValueError):     # names a later segment
+        engine.align_batch(config, [lpz, lpz], lab, ubs, emission_of=[1, 1])
+    with pytest.raises(ValueError):     # the named segment has no emissions of its own
+        engine.align_batch(config, [lpz, lpz, lpz], lab + [lab[1]], ubs + [ubs[1]], emission_of=[0, 0, 1])
+    with pytest.raises(ValueError):     # another number of frames
+        engine.align_batch(config, [lpz, lpz[:150]], lab, ubs, emission_of=[0, 0], shapes=[(200, 32), (150, 32)])
+    with pytest.raises(ValueError):
+        engine.align_batch(config, [lpz, lpz], lab, ubs, emission_of=[0])
+    # the caller may vouch for the prefix property (labels=None): plan only
+    plan = engine.plan(config, 32, [200, 200], [len(lab[0]), len(lab[1])], [3, 2], emission_of=[0, 0], labels=None)
+    assert plan.sharing() == (1, 1)
+    plan.close()

@@ -113,3 +113,27 @@ def test_classic_text_converter_end_to_end(pkg, oracle):
         a, b = hip.get_segments(ta), ref.get_segments(tb)
         assert [s[:2] for s in a["segments"]] == [s[:2] for s in b["segments"]]
         np.testing.assert_allclose([s[2] for s in a["segments"]], [s[2] for s in b["segments"]], rtol=0, atol=SCORE_TOL)
+
+
+def test_label_width_limits(pkg, oracle):
+    """Sixteen characters per token is what the kernel takes; wider matrices are refused before the launch."""
+    rng = np.random.default_rng(8)
+    V = 40
+    T, C, S = 300, 40, 16
+    mat = np.full((C, S), -1, np.int64)
+    mat[1:, 0] = rng.integers(1, V, size=C - 1)
+    mat[0] = -1
+    for c in range(S, C, 5):           # a few long tokens, up to 16 characters
+        mat[c, int(rng.integers(1, S))] = int(rng.integers(1, V))
+    mat[C - 1, :] = -1
+    mat[C - 1, 0] = 0                  # closing blank
+    ub = np.asarray([1, C - 1], np.int64)
+    mat[1, 0] = 0
+    logits = rng.normal(size=(T, V)).astype(np.float32)
+    lpz = (logits - np.log(np.exp(logits).sum(axis=1, keepdims=True))).astype(np.float32)
+    segs = [(lpz, mat, ub)]
+    _check(oracle, segs, _run(pkg, segs))
+    wide = np.concatenate([mat, np.full((C, 1), -1, np.int64)], axis=1)
+    wide[20, 16] = 3
+    with pytest.raises(NotImplementedError):
+        _run(pkg, [(lpz, wide, ub)])
