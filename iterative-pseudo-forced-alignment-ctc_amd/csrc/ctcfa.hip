@@ -500,9 +500,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             }
         }
     pl->gather = gather;
-    // Vocabularies staged row by row (33..128 entries other than the vectorised pitch 64) take two
-    // producer waves, each staging every other row: one alone cannot keep six tiles fed.
-    const int nprod = (!gather && pl->VP > 32 && !(pl->VP == 64 && vocab == 64)) ? 2 : 1;
+    // Vocabularies above 32 entries take two producer waves, each staging half the rows of every block: one
+    // alone cannot keep six tiles fed.
+    const int nprod = (!gather && pl->VP > 32) ? 2 : 1;
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.

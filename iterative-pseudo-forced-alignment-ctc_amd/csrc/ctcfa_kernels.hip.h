@@ -278,6 +278,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // tiles on its SIMD starve it and the whole workgroup runs at the producer's pace.
         __builtin_amdgcn_s_setprio(CTCFA_PRODUCER_PRIO);
         const int part = my.stage;  // which share of the rows (nprod == 2), and which staged[] counter
+        int fix_mode = 0;           // how two producers split a block: 0 every other row, 2 every other group of four rows
         constexpr int PASSES = kRows * VP / 64;
         constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
@@ -310,8 +311,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // (one store per block, after the rows' own stores -- LDS executes a wave's operations in order; nothing
             // in the per-row code, so nothing in the way when the flag is off)
             if (gratis) {
+                // the rows of the block this wave staged: all of them; every other one; every other group of four
                 const int nmine = roles->nprod == 2 ? kRows / 2 : kRows;
-                const int row = roles->nprod == 2 ? part + 2 * lane : lane;
+                const int row = roles->nprod != 2 ? lane : fix_mode == 2 ? ((lane >> 2) * 2 + part) * 4 + (lane & 3) : part + 2 * lane;
                 if (lane < nmine)
                     *reinterpret_cast<float*>(smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) +
                                               static_cast<uint32_t>(row * (PITCH * 8) + blank * 8 + 4)) = 0.0f;
@@ -372,7 +374,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // entries of a row with one dwordx4, LPR lanes share a row, RPP rows per pass.
             constexpr int LPR = VP / 4;
             constexpr int RPP = 64 / LPR;
-            constexpr int NP = (VP <= 64) ? kRows / RPP : 1;  // 4 (VP=32) or 8 (VP=64) passes per block
+            constexpr int NPB = (VP <= 64) ? kRows / RPP : 1;  // 4 (VP=32) or 8 (VP=64) passes per block
+            // 64 entries: two producers, each takes every other pass (four rows) of a block -- four passes and
+            // two register sets per wave, like the single producer of the 32-entry case (one producer with
+            // one set had a block's HBM latency in front of every block: 207 us)
+            constexpr int PSTEP = (VP == 64) ? 2 : 1;
+            constexpr int NP = NPB / PSTEP;
             const int lr = lane / LPR;
             const int lv = (lane % LPR) * 4;
             const int blank_lane = lr * LPR + blank / 4;  // lane of my row that holds the blank entry
@@ -380,10 +387,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             auto vload = [&](int jb, float4 (&e)[NP]) {
                 const int t0 = jb * kRows + 1 + lr;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int p = pp * PSTEP + (PSTEP == 2 ? part : 0);
                     int t = t0 + p * RPP;
                     t = t < T ? t : T - 1;
-                    e[p] = *reinterpret_cast<const float4*>(lpz_bytes + static_cast<uint32_t>(t * V + lv) * 4u);
+                    e[pp] = *reinterpret_cast<const float4*>(lpz_bytes + static_cast<uint32_t>(t * V + lv) * 4u);
                 }
             };
             auto vwrite = [&](int jb, const float4 (&e)[NP]) {
@@ -394,8 +402,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                                : sink_base + static_cast<uint32_t>(lane * 8);
                 const int t0 = jb * kRows + 1 + lr;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const float4 v = e[p];
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int p = pp * PSTEP + (PSTEP == 2 ? part : 0);
+                    const float4 v = e[pp];
                     notneg |= !(max3f(v.x, v.y, __builtin_fmaxf(v.z, v.w)) <= 0.0f) | (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
                     const float mine = blank_comp == 0 ? v.x : (blank_comp == 1 ? v.y : (blank_comp == 2 ? v.z : v.w));
                     const float lb = __shfl(mine, blank_lane);
@@ -412,7 +421,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     *reinterpret_cast<float2*>(smem + spc + ((lv == 0) ? p * (RPP * PITCH * 8) : 0)) = sp;
                 }
             };
-            if constexpr (VP == 32) {   // two register sets: loads run a block ahead of the LDS writes
+            if constexpr (PSTEP == 2) fix_mode = 2;
+            {   // two register sets: loads run a block ahead of the LDS writes
                 // (a third set -- loads two blocks ahead -- measured no faster, and does not fit the
                 // 64-register budget of the narrow tiles)
                 float4 ea[NP], eb[NP];
@@ -427,15 +437,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     wait_space(jb + 1);
                     vwrite(jb + 1, eb);
                     publish(jb + 1);
-                }
-            } else {   // 64 entries: one set (32 registers; a second one would not fit the 64-register budget)
-                float4 ea[NP];
-                vload(0, ea);
-                for (int jb = 0; jb < nblk; ++jb) {
-                    wait_space(jb);
-                    vwrite(jb, ea);
-                    publish(jb);
-                    if (jb + 1 < nblk) vload(jb + 1, ea);
                 }
             }
         } else if constexpr (VP > 32 && VP <= 64) {
@@ -1397,7 +1398,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                             slot[r * PB] = make_float2(is_pseudo ? -__builtin_inff() : e[r], is_pseudo ? pm : m);
                         }
                     }
-                    if (V == 64 && lane == 0) {
+                    if (V == 64 && !preamble && lane == 0) {   // (with the preamble flag: written once, below)
 #pragma unroll
                         for (int r = 0; r < kHalf; ++r) {
                             const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
@@ -1455,6 +1456,10 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         if (j >= 1) step(j - 1, s1);
                     }
                 };
+                // 64 entries leave no lane for the start column's pseudo entry; under preamble_transition_cost_zero it
+                // is the same (-inf, 0) in every row of every block: written once
+                if (V == 64 && preamble && lane < kHalf)
+                    ering[(r0 + lane) * PB + PB - 1] = make_float2(-__builtin_inff(), 0.0f);
                 if (PB == 33 && V == 32) run(issue4, put4, q0, q1);
                 else run(issue, put, e0, e1);
                 __builtin_amdgcn_s_setprio(0);
