@@ -500,9 +500,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             }
         }
     pl->gather = gather;
-    // Vocabularies above 32 entries take two producer waves, each staging half the rows of every block: one
-    // alone cannot keep six tiles fed.
-    const int nprod = (!gather && pl->VP > 32) ? 2 : 1;
+    // Every vocabulary but the 32-entry one (whose rows a single wave moves with four wide loads per block) takes
+    // two producer waves, each staging half the rows of every block: one alone cannot keep six tiles fed.
+    const int nprod = (!gather && (pl->VP > 32 || vocab < 32)) ? 2 : 1;
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.

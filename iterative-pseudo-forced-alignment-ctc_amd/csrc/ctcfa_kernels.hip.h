@@ -278,9 +278,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // tiles on its SIMD starve it and the whole workgroup runs at the producer's pace.
         __builtin_amdgcn_s_setprio(CTCFA_PRODUCER_PRIO);
         const int part = my.stage;  // which share of the rows (nprod == 2), and which staged[] counter
-        int fix_mode = 0;           // how two producers split a block: 0 every other row, 2 every other group of four rows
+        int fix_mode = 0;           // how two producers split a block: 0 every other row, 2 every other group of four rows, 3 halves
         constexpr int PASSES = kRows * VP / 64;
-        constexpr int CH = PASSES < 16 ? PASSES : 16;  // loads in flight per chunk
+        constexpr int CH = PASSES < 16 ? PASSES : (VP == 32 ? 8 : 16);  // passes per chunk (VP == 32: half a block, one per producer)
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
         bool notneg = false;  // any staged emission that is not <= 0 (NaN counts)
 #ifdef CTCFA_STAMP
@@ -313,7 +313,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             if (gratis) {
                 // the rows of the block this wave staged: all of them; every other one; every other group of four
                 const int nmine = roles->nprod == 2 ? kRows / 2 : kRows;
-                const int row = roles->nprod != 2 ? lane : fix_mode == 2 ? ((lane >> 2) * 2 + part) * 4 + (lane & 3) : part + 2 * lane;
+                const int row = roles->nprod != 2 ? lane : fix_mode == 2 ? ((lane >> 2) * 2 + part) * 4 + (lane & 3)
+                                : fix_mode == 3 ? part * (kRows / 2) + lane : part + 2 * lane;
                 if (lane < nmine)
                     *reinterpret_cast<float*>(smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) +
                                               static_cast<uint32_t>(row * (PITCH * 8) + blank * 8 + 4)) = 0.0f;
@@ -510,18 +511,26 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // (Tried in round 2 and dropped: dwordx2 loads with two or three rows per pass for even vocabularies --
             // fewer passes, but lane-varying row addresses and store targets; V = 38: 183 us against 166.)
             run(std::integral_constant<int, 2>{});   // (the plan always gives this path two producers)
-        } else if constexpr (PASSES == CH) {
-            // whole block in one chunk (VP == 32, V < 32).  One register set: the loads of block jb+1 are
-            // issued right after block jb has been written (the ring keeps the tiles fed meanwhile; a
-            // second set would cost every wave of the kernel 16 VGPRs and with them the 64-register
-            // budget that lets two backtrack workgroups sit beside two fill workgroups on a CU)
-            float ea[CH];
-            load_chunk(0, 0, ea);
-            for (int jb = 0; jb < nblk; ++jb) {
+        } else if constexpr (VP == 32) {
+            // V < 32 (e.g. the 29..31 entries of English character models): a lane loads one entry, two rows per
+            // pass; two producers, each stages one half (16 rows, 8 passes) of every block with two register sets
+            // -- the loads of a block are issued a whole block before they are written.  (One producer with one
+            // set of 16 had a block's HBM latency in front of every block: 212 us at V = 20; two sets of 16 in
+            // one wave do not fit the 64 registers the narrow tiles are held to.)
+            fix_mode = 3;
+            const int p0 = part * CH;
+            float ea[CH], eb[CH];
+            load_chunk(0, p0, ea);
+            for (int jb = 0; jb < nblk; jb += 2) {
+                if (jb + 1 < nblk) load_chunk(jb + 1, p0, eb);
                 wait_space(jb);
-                write_chunk(jb, 0, ea);
+                write_chunk(jb, p0, ea);
                 publish(jb);
-                if (jb + 1 < nblk) load_chunk(jb + 1, 0, ea);
+                if (jb + 1 >= nblk) break;
+                if (jb + 2 < nblk) load_chunk(jb + 2, p0, ea);
+                wait_space(jb + 1);
+                write_chunk(jb + 1, p0, eb);
+                publish(jb + 1);
             }
         } else if constexpr (VP > 64) {
             // ---- character vocabularies between 65 and 128 entries (e.g. 76 for French): a row per
@@ -1389,12 +1398,22 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                 auto put = [&](int jb, const float (&e)[kHalf]) {
                     if (jb < 0) return;
                     float2* slot = ering + r0 * PB + woff;
-                    if (lane <= V) {
+                    if (preamble) {
+                        // (the start column's entry is (-inf, 0) in every row: written once, below -- three
+                        // instructions per row here instead of six; the producers are on the step's critical path)
+                        if (lane < V) {
+#pragma unroll
+                            for (int r = 0; r < kHalf; ++r) {
+                                const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
+                                slot[r * PB] = make_float2(e[r], max3f(lb, e[r], kProbMax));
+                            }
+                        }
+                    } else if (lane <= V) {
 #pragma unroll
                         for (int r = 0; r < kHalf; ++r) {
                             const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
                             const float m = max3f(lb, e[r], kProbMax);
-                            const float pm = preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax);  // start column's stay step
+                            const float pm = __builtin_fmaxf(lb, kProbMax);  // start column's stay step
                             slot[r * PB] = make_float2(is_pseudo ? -__builtin_inff() : e[r], is_pseudo ? pm : m);
                         }
                     }
@@ -1456,9 +1475,9 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
                         if (j >= 1) step(j - 1, s1);
                     }
                 };
-                // 64 entries leave no lane for the start column's pseudo entry; under preamble_transition_cost_zero it
-                // is the same (-inf, 0) in every row of every block: written once
-                if (V == 64 && preamble && lane < kHalf)
+                // Under preamble_transition_cost_zero the start column's pseudo entry is the same (-inf, 0) in every
+                // row of every block: written once (64 entries leave no lane for it anyway)
+                if (preamble && lane < kHalf && !(PB == 33 && V == 32))
                     ering[(r0 + lane) * PB + PB - 1] = make_float2(-__builtin_inff(), 0.0f);
                 if (PB == 33 && V == 32) run(issue4, put4, q0, q1);
                 else run(issue, put, e0, e1);
