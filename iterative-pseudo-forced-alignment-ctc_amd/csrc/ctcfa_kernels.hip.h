@@ -468,15 +468,14 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 auto rwrite = [&](int jb, const float (&e)[NR]) {
                     unsigned char* dst = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) + ent +
                                          static_cast<uint32_t>(part * (PITCH * 8));
-                    const int t0 = jb * kRows + 1 + part;
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
+                        // (rows past the end of the segment repeat its last row -- the loads are clamped: nothing
+                        // downstream reads what the tiles make of them, so they are not zeroed here)
                         const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), blank));
-                        const bool valid = (t0 + i * PARTS) < T;  // uniform
                         notneg |= !(e[i] <= 0.0f);
                         float2 v = make_float2(e[i], max3f(lb, e[i], kProbMax));
                         if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                        if (!valid) v = (lane == kPseudoLane) ? make_float2(-__builtin_inff(), 0.0f) : make_float2(0.f, 0.f);
                         *reinterpret_cast<float2*>(dst + i * (PARTS * PITCH * 8)) = v;
                     }
                 };
