@@ -534,8 +534,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         } else if constexpr (VP > 64) {
             // ---- character vocabularies between 65 and 128 entries (e.g. 76 for French): a row per
             // pass, lane i holds entries i and 64 + i; lane 0 also writes the start-column pseudo entry.
-            // With two producers each stages every other row.  One register set per producer: the loads
-            // of block jb+1 are issued right after block jb has been written.
+            // Two producers, each stages every other row.  Under preamble_transition_cost_zero the start-column entry
+            // is written once for the whole ring; rows past the end of the segment repeat its last row (nothing
+            // reads what follows).
             const int sv0 = lane < V ? lane : V - 1;
             const int sv1 = lane + 64 < V ? lane + 64 : V - 1;
             auto runw = [&](auto parts_tag) {
@@ -558,27 +559,20 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     unsigned char* d0 = slot + static_cast<uint32_t>((lane < V ? lane : VP + 1) * 8);
                     unsigned char* d1 = slot + static_cast<uint32_t>((lane + 64 < V ? lane + 64 : VP + 1) * 8);
                     unsigned char* dp = slot + static_cast<uint32_t>((lane == 0 ? VP : VP + 1) * 8);
-                    const int t0 = jb * kRows + 1 + part;
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const float lb = (blank < 64)
                                              ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e0[r]), blank & 63))
                                              : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1[r]), blank & 63));
-                        const bool valid = (t0 + r * PARTS) < T;  // uniform
                         notneg |= !(e0[r] <= 0.0f) | !(e1[r] <= 0.0f);
-                        float2 v0 = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
-                        float2 v1 = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
-                        float2 vp = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                        if (!valid) {
-                            v0 = make_float2(0.f, 0.f);
-                            v1 = v0;
-                            vp = make_float2(-__builtin_inff(), 0.0f);
-                        }
-                        *reinterpret_cast<float2*>(d0 + r * (PARTS * PITCH * 8)) = v0;
-                        *reinterpret_cast<float2*>(d1 + r * (PARTS * PITCH * 8)) = v1;
-                        *reinterpret_cast<float2*>(dp + r * (PARTS * PITCH * 8)) = vp;
+                        *reinterpret_cast<float2*>(d0 + r * (PARTS * PITCH * 8)) = make_float2(e0[r], max3f(lb, e0[r], kProbMax));
+                        *reinterpret_cast<float2*>(d1 + r * (PARTS * PITCH * 8)) = make_float2(e1[r], max3f(lb, e1[r], kProbMax));
+                        if (!preamble)   // (uniform)
+                            *reinterpret_cast<float2*>(dp + r * (PARTS * PITCH * 8)) = make_float2(-__builtin_inff(), __builtin_fmaxf(lb, kProbMax));
                     }
                 };
+                // One register set per producer (a second one -- 64 more registers -- spills under the 128 a
+                // 16-wave workgroup may use): the loads of block jb+1 are issued right after block jb has been written.
                 float ea[NR], eb[NR];
                 wload(0, ea, eb);
                 for (int jb = 0; jb < nblk; ++jb) {
@@ -588,8 +582,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     if (jb + 1 < nblk) wload(jb + 1, ea, eb);
                 }
             };
-            if (roles->nprod == 2) runw(std::integral_constant<int, 2>{});
-            else runw(std::integral_constant<int, 1>{});
+            if (preamble && part == 0)   // start-column entry of every row of the ring, once
+                for (int idx = lane; idx < NS * kRows; idx += 64)
+                    *reinterpret_cast<float2*>(smem + static_cast<uint32_t>((idx / kRows) * SLOT_BYTES + (idx % kRows) * (PITCH * 8) + VP * 8)) =
+                        make_float2(-__builtin_inff(), 0.0f);
+            runw(std::integral_constant<int, 2>{});   // (the plan always gives these vocabularies two producers)
         }
         return;
     }
