@@ -225,7 +225,7 @@ int waves_of(int W, int nprod) {
 int lds_bytes_fill(int NS, int W, int K, int VP, int nwatch = 0) {
     // emission ring (NS slots) + exchange rings + last-column ring + counters + sink
     // (+ shared fills: a ring and a target offset per watch column)
-    return NS * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + W * ctcfa::kGroups * NS * ctcfa::halo_lanes(K) * K * 4 +
+    return NS * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + W * ctcfa::kExchangeRing * ctcfa::halo_lanes(K) * K * 4 +
            64 * 4 + ctcfa::kFlagInts * 4 + ctcfa::kSinkBytes + nwatch * (64 * 4 + 8);
 }
 
@@ -262,7 +262,7 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
     ShapeChoice best{0, 0, 0};
     const int wg_per_cu_needed = std::max(1, (B + num_cu - 1) / num_cu);
     int ns_forced = 0;
-    if (const char* e = std::getenv("CTCFA_NS")) ns_forced = std::max(2, std::min(8, std::atoi(e)));
+    if (const char* e = std::getenv("CTCFA_NS")) ns_forced = std::max(2, std::min(ctcfa::kExchangeRing / ctcfa::kGroups, std::atoi(e)));   // (a tile may run 2 NS groups ahead of its neighbour: the exchange ring has 8 slots)
     const double x = ckpt ? 0.0 : 6.0;   // extra vector instructions per cell for the decision math
     auto r512 = [](int v) { return (v + 511) / 512 * 512; };  // LDS is handed out in 512-byte units
     for (int K : kKs) {

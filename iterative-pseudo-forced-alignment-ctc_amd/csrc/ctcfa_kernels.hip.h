@@ -146,6 +146,7 @@ constexpr int kGroups = kRows / kHaloRows;
 #endif
 constexpr int kPollLead = CTCFA_POLL_LEAD;   // a tile asks for its neighbour's group this many rows before it needs it
 constexpr int kPeekLead = CTCFA_PEEK_LEAD;   // ... and reads the counter this many rows before it looks at the value
+constexpr int kExchangeRing = 8;    // group slots of a tile's exchange ring (ring slots NS <= 4, two groups per block)
 constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, pad
 constexpr int kBigCount = 0x3fffffff;
 constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a lost counter must not hang the GPU
@@ -227,7 +228,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const WaveRole my = roles->wave[wave_id];
     const int W = roles->nstages;         // compute tiles
     const int NS = roles->nslots;         // emission ring slots
-    const int XR = kGroups * NS;          // exchange ring: groups a tile can be ahead of its right neighbour
+    constexpr int XR = kExchangeRing;     // exchange ring: groups a tile can be ahead of its right neighbour (>= 2 NS; a power of two: g % XR is an AND)
     const int w = my.stage;               // this wave's tile (compute waves)
 
     const SegDesc sd = segs[blockIdx.x];
@@ -853,7 +854,19 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             }
             if (i % kHaloRows == kHaloRows - 1) {   // group end: my last columns for the tile to my right, then the counter
-                if (publishes && (CTCFA_ABL < 4 || i == kRows - 1)) {
+                if constexpr (K <= 4) {
+                    // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data
+                    if (CTCFA_ABL < 4 || i == kRows - 1) {
+                        float* xw = reinterpret_cast<float*>(smem + (publishes ? xout_addr + static_cast<uint32_t>((g % XR) * XW * 4)
+                                                                               : sink_base + static_cast<uint32_t>(lane * 16)));
+                        if (CTCFA_ABL < 3) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) xw[k] = prev[k];
+                        }
+                        asm volatile("" ::: "memory");
+                        if (lane == 63) flags[w] = g + 1;
+                    }
+                } else if (publishes && (CTCFA_ABL < 4 || i == kRows - 1)) {
                     float* xw = reinterpret_cast<float*>(smem + xout_addr + static_cast<uint32_t>((g % XR) * XW * 4));
                     if (CTCFA_ABL < 3) {
 #pragma unroll
