@@ -854,8 +854,10 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             }
             if (i % kHaloRows == kHaloRows - 1) {   // group end: my last columns for the tile to my right, then the counter
-                if constexpr (K <= 4) {
-                    // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data
+                if constexpr (K == 1) {
+                    // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data.
+                    // One-column tiles only: with more columns per lane 64 lanes' worth of LDS writes cost more than
+                    // the branch (K = 3, 4096 segments: +9 %), with one column the chain of 14 tiles gains 8 %.
                     if (CTCFA_ABL < 4 || i == kRows - 1) {
                         float* xw = reinterpret_cast<float*>(smem + (publishes ? xout_addr + static_cast<uint32_t>((g % XR) * XW * 4)
                                                                                : sink_base + static_cast<uint32_t>(lane * 16)));
