@@ -714,6 +714,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #define CTCFA_STAMP_END(acc, cnt) do { } while (0)
 #endif
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
+    int jslot = 0;     // j % NS of the block loop below
 
     // scores of the watch columns of this tile, rows 32j .. 32j+31 (from the rings, or -1e9 for a
     // block the tile skipped), to where the members' backtracks look for them
@@ -730,7 +731,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // OWNER 2 (shared fill): it holds watch columns, each in some lane at some k
     auto block = [&](int j, auto owner_tag) {
         constexpr int OWNER = decltype(owner_tag)::value;
-        const int slot = j % NS;
+        const int slot = jslot;   // j % NS, kept by the block loop (NS is 3 or 4: a division otherwise)
         const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
         cur_slot = slot;
 #pragma unroll
@@ -898,7 +899,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         if constexpr (OWNER == 2) watch_out(j, true);
     };
 
-    for (int j = 0; j <= jlast; ++j) {
+    for (int j = 0; j <= jlast; ++j, jslot = (jslot + 1 == NS) ? 0 : jslot + 1) {
         staged_seen = __builtin_amdgcn_readfirstlane(peek_sa < peek_sb ? peek_sa : peek_sb);
 #if CTCFA_TILE_PRIO == 3
         if (w == 0) {   // (tile 0 has no neighbour to its left: it steps back when it runs into the producer)
