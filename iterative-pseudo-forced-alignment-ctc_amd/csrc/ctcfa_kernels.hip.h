@@ -614,7 +614,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const bool is_halo = (w > 0) && (lane < HL);   // tile 0's first lanes are left padding: they reproduce table[t,0] themselves
     const int wstar = sd.owner_stage;  // tile that owns the last label column (ragged batches: <= W-1)
     const int lstar = sd.owner_lane;
-    float4 pub4 = make_float4(kProbMax, kProbMax, kProbMax, kProbMax);  // .x = row 0 of every label column
+    bool ring_has_row0 = false;   // owner tiles: entry 0 of the current ring half holds the row the block before ended in
     // Shared fill: the watch columns this tile owns (halo lanes hold copies, not columns) are slots
     // [ws_lo, ws_hi) of the group's list; the lane that holds slot `myslot` has it at k == ksel.
     int ws_lo = 0, ws_hi = 0, myslot = -1, ksel = K - 1;
@@ -736,9 +736,20 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         cur_slot = slot;
 #pragma unroll
         for (int k = 0; k < K; ++k) gaddr[k] += delta;
-        uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 16);
-        if (OWNER == 1 && lane == lstar) out_addr = lcring_base + static_cast<uint32_t>((j & 1) * kRows * 4);
-        if (OWNER == 2 && myslot >= 0) out_addr = wring_base + static_cast<uint32_t>((myslot * 64 + (j & 1) * kRows) * 4);
+        // Owner tiles publish the score of their watched column after every row: ring entry q of the half (j & 1)
+        // holds table row 32 j + q, so row i goes to entry i + 1 and the block's last row to entry 0 of the OTHER
+        // half.  One ds_write_b32 per row straight from the register (every lane stores; the lanes that watch
+        // nothing into the sink) -- no vector instruction, where collecting four rows for a wider store cost a v_mov
+        // per row on the tile everybody else ends up waiting for.
+        uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 4);
+        if (OWNER == 1 && lane == lstar) out_addr = lcring_base;
+        if (OWNER == 2 && myslot >= 0) out_addr = wring_base + static_cast<uint32_t>(myslot * 64 * 4);
+        const uint32_t half_cur = static_cast<uint32_t>((j & 1) * kRows * 4), half_nxt = static_cast<uint32_t>(((j + 1) & 1) * kRows * 4);
+        if constexpr (OWNER != 0) {
+            if (!ring_has_row0)   // the block before was skipped (or there is none): its last row is -1e9 in every label column
+                *reinterpret_cast<float*>(smem + out_addr + half_cur) = kProbMax;
+            ring_has_row0 = true;
+        }
 
         // software pipeline: operands of row i+PF are requested while row i is computed
         constexpr int PF = CTCFA_PF;
@@ -792,13 +803,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #pragma unroll
                     for (int k = 0; k < K - 1; ++k) pv = (ksel == k) ? prev[k] : pv;
                 }
-                if ((i + 1) % 4 == 0) pub4.x = pv;
-                else if ((i + 1) % 4 == 1) pub4.y = pv;
-                else if ((i + 1) % 4 == 2) pub4.z = pv;
-                else {
-                    pub4.w = pv;
-                    *reinterpret_cast<float4*>(smem + out_addr + (i - 2) * 4) = pub4;
-                }
+                *reinterpret_cast<float*>(smem + out_addr + (i + 1 < kRows ? half_cur + static_cast<uint32_t>((i + 1) * 4) : half_nxt)) = pv;
             }
             // Pin this row's decisions here (empty asm = opaque use, no instruction): dec[] is
             // consumed at the end of the block, and LLVM otherwise sinks the residual math of
@@ -956,12 +961,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     }
     return;
 #endif
-    // row 32*nblk (present when (T-1) % 32 == 0) is still in pub4.x
+    // row 32*nblk (present when (T-1) % 32 == 0): what the watched column holds after the last block
+    float pv_end = prev[K - 1];
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) pv_end = (ksel == k) ? prev[k] : pv_end;
     if (wn > 0) {
         if (myslot >= 0 && nblk * kRows < T)
-            lastcol[*reinterpret_cast<const int64_t*>(smem + wtab_base + myslot * 8) + nblk * kRows] = pub4.x;
+            lastcol[*reinterpret_cast<const int64_t*>(smem + wtab_base + myslot * 8) + nblk * kRows] = pv_end;
     } else if (w == wstar && lane == lstar && nblk * kRows < T) {
-        seg_lastcol[nblk * kRows] = pub4.x;
+        seg_lastcol[nblk * kRows] = pv_end;
     }
 }
 
