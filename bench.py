@@ -105,6 +105,7 @@ def roofline_entry(fill_ms, bt_ms, ms_per_step, stride, fill_bytes, step_bytes, 
             traffic = None
     return {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": detail, "traffic_source": src,
+            "traffic_note": "fabric bytes (Infinity-Cache hits included): the bench re-reads the same emissions every step, under the 256 MiB MALL",
             "algorithmic_bytes_per_launch": fill_bytes,
             "algorithmic_bytes_note": "fill kernel only: 4TV + TC/8 per segment (the whole step, backtrack included: step_algorithmic_bytes)",
             "kernel_ms_avg": float(np.mean(fill_ms)), "kernel_ms_min": float(np.min(fill_ms)),
@@ -261,7 +262,7 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
         step()
     drain()
     barrier()
-    stride = args.timing_stride if args.timing_stride > 0 else (1 if args.steps < 16 else 4)
+    stride = args.timing_stride if args.timing_stride > 0 else (1 if args.steps <= 64 else 4)
     n_timed = min((args.steps + stride - 1) // stride, 256)
     for g in G:
         g["plan"].set_timing(max(n_timed, 4))
@@ -320,7 +321,7 @@ def run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu):
         out = {
             "metric": "aligned audio hours/sec (CTC DP frames/s)",
             "value": fps * INDEX_DURATION / 3600.0, "unit": "audio-hours/s", "frames_per_s": fps,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, **dist_info(dist, rehearsal), "steps": args.steps, "warmup": args.warmup,
             "spinup": {"steps": n_spin, "note": "untimed passes (<= 0.3 s) before the warm-up steps: clock ramp from idle"},
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -356,17 +357,71 @@ def cpu_baseline_child(args):
         return {"error": repr(exc)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a bare shell (no torch.distributed.run around it): this process
+    never touches the GPU.  It times the CPU baseline first (the host cores are then free of rank
+    processes), starts the N ranks as CHILDREN -- one process per GPU, the reference's n_process workers
+    (/root/reference/align_utterances.sh:57,127-137) -- relays rank 0's JSON line and leaves with the
+    children's worst return code."""
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    cpu_file = None
+    if args.cpu_sample > 0:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        cpu = cpu_baseline_child(args)
+        fd, cpu_file = tempfile.mkstemp(prefix="ctcfa_cpu_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(cpu, f)
+        env0["CTCFA_BENCH_CPU_BASELINE"] = cpu_file
+    # (one build, before N ranks race for the lock)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, env=env0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CTCFA_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], cwd=ROOT, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    if cpu_file:
+        os.unlink(cpu_file)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    raise SystemExit(bad[0] if bad else 0)
+
+
+def dist_info(dist, rehearsal):
+    """What the collective layer itself reports (the driver checks the rank count against --gpus)."""
+    if dist is None:
+        return {"ranks_seen": 1, "backend": None}
+    return {"ranks_seen": dist.get_world_size(), "backend": ("gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL)")}
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)   # GPU-free launcher; the ranks come back through main() with WORLD_SIZE set
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        # (build the oracle first: the child only needs the C restatement)
-        import subprocess
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-        cpu = cpu_baseline_child(args)
+    if rank == 0 and args.cpu_sample > 0:
+        pre = os.environ.get("CTCFA_BENCH_CPU_BASELINE")   # timed by the launcher above, before the ranks existed
+        if pre and os.path.exists(pre):
+            cpu = json.load(open(pre))
+        else:
+            # (build the oracle first: the child only needs the C restatement)
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+            cpu = cpu_baseline_child(args)
     import torch
     import __graft_entry__ as ge
 
@@ -492,7 +547,7 @@ def main():
     # Kernel durations come from HIP events recorded around every `stride`-th launch of the timed
     # region: an event record is a packet the queue retires between two kernels (~5 us each), and
     # bracketing every launch would itself take ~4 % off the number being measured.
-    stride = args.timing_stride if args.timing_stride > 0 else (1 if args.steps < 16 else 4)
+    stride = args.timing_stride if args.timing_stride > 0 else (1 if args.steps <= 64 else 4)
     n_timed = min((args.steps + stride - 1) // stride, 1024)
     plan.set_timing(max(n_timed, 4))
     plan.set_timing_stride(stride)
@@ -537,7 +592,7 @@ def main():
         out = {
             "metric": "aligned audio hours/sec (CTC DP frames/s)",
             "value": value, "unit": "audio-hours/s", "frames_per_s": fps,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, **dist_info(dist, rehearsal), "steps": args.steps, "warmup": args.warmup,
             "spinup": {"steps": args.spinup_steps, "note": "untimed, before the warm-up steps: clock ramp from idle"},
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
