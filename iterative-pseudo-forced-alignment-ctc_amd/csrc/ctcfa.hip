@@ -53,6 +53,9 @@ struct ctcfa_plan {
     int B = 0, V = 0, K = 0, W = 0, VP = 0;
     int lds_fill = 0, lds_bt = 0, rec_bytes = 0, lab_bytes = 0, nblk_max = 0;
     bool ckpt = false;  // fill stores table rows, the backtrack recomputes its decisions (V <= 64)
+    int bt_waves = 4;   // waves of a backtrack workgroup (checkpoint mode: striders, one 32-row block each)
+    int bt_scorers = 0; // ... plus waves that only score utterances (checkpoint mode, plans with utterances)
+    int fol_bytes = 0;  // checkpoint mode: LDS copy of frame_of_label
     bool have_utt = false;
     std::vector<SegDesc> segs;
     int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
@@ -170,6 +173,32 @@ FillFn select_fill(int K, int VP, bool ck) {
 #endif
         default: return nullptr;
     }
+}
+
+using StrideFn = void (*)(ctcfa::BtArgs);
+StrideFn select_strider(int VP) {
+    switch (VP) {
+        case 32: return ctcfa::stride_backtrack_kernel<32>;
+#ifndef CTCFA_DEV_VP32_ONLY
+        case 40: return ctcfa::stride_backtrack_kernel<40>;
+        case 48: return ctcfa::stride_backtrack_kernel<48>;
+        case 56: return ctcfa::stride_backtrack_kernel<56>;
+        case 64: return ctcfa::stride_backtrack_kernel<64>;
+#endif
+        default: return nullptr;
+    }
+}
+
+// checkpoint-mode backtrack: waves per workgroup (each recomputes and walks one 32-row block at a time)
+int strider_waves() {
+    int n = 3;   // (beside the fill of the next batch more striders cost the fill more than they save: 3 + 1 scorer = 4 waves, one per SIMD)
+    if (const char* e = std::getenv("CTCFA_SB_WAVES")) n = std::atoi(e);
+    return std::max(1, std::min(ctcfa::kSbMaxWaves - 1, n));   // (one more wave may join them as a scorer)
+}
+
+// dynamic LDS of one checkpoint-mode backtrack workgroup: rec | labels | frame_of_label | -inf column + NW slots | char_probs
+int lds_bytes_strider(int rec_bytes, int lab_bytes, int VP, int nw, int T) {
+    return rec_bytes + lab_bytes + 4 * lab_bytes + (nw + 1) * ctcfa::kRows * VP * 4 + T * 4;
 }
 
 // columns a tile of K columns per lane adds to the trellis (its halo lanes are copies)
@@ -588,8 +617,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     {
         const int Tb = Tmax;
         const int rec = ((Tb + ctcfa::kRows - 1) / ctcfa::kRows * 8 + 15) / 16 * 16;
-        const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8 + 256;
-        bt_lds_estimate = pl->ckpt ? rec + (Cmax + 15) / 16 * 16 + std::max(Tb * 4, ring) : rec + Tb * 4;
+        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VP, strider_waves(), Tb) : rec + Tb * 4;
     }
     ShapeChoice shape{0, 0, 0};
     if (gather) {
@@ -747,8 +775,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             for (int b = 0; b < batch; ++b)
                 if (pl->segs[b].prestatus == CTCFA_ST_OK) Cbt = std::max(Cbt, (int)C[b]);
             pl->lab_bytes = (Cbt + 15) / 16 * 16;   // one byte per label
-            const int ring = ctcfa::kRows * (vocab <= 32 ? 33 : 65) * 8;
-            pl->lds_bt = pl->rec_bytes + pl->lab_bytes + std::max(Tbt * 4, ring + 256);  // + 64 decision words, recompute wave -> walker
+            pl->bt_waves = strider_waves();
+            pl->bt_scorers = (pl->have_utt && !std::getenv("CTCFA_SB_NO_SCORER")) ? 1 : 0;
+            pl->fol_bytes = 4 * pl->lab_bytes;
+            pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VP, pl->bt_waves, Tbt);
         }
     }
     if (pl->lds_bt > eng->lds_limit) {
@@ -808,8 +838,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
     if (pl->lds_bt > 48 * 1024)
         PLAN_TRY(hipFuncSetAttribute(!pl->ckpt ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel<0>)
-                                     : pl->V <= 32 ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel<33>)
-                                                   : reinterpret_cast<const void*>(ctcfa::backtrack_kernel<65>),
+                                                : reinterpret_cast<const void*>(select_strider(pl->VP)),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
     if (!pl->win_list.empty()) {
         PLAN_TRY(hipMalloc(&pl->d_win_list, sizeof(int32_t) * pl->win_list.size()));
@@ -940,6 +969,8 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.L = pl->prm.score_min_mean_over_L;
     bp.rec_bytes = pl->rec_bytes;
     bp.lab_bytes = pl->lab_bytes;
+    bp.fol_bytes = pl->fol_bytes;
+    bp.scorers = pl->ckpt ? pl->bt_scorers : 0;
     bp.dur = pl->prm.index_duration;
     const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
                            pl->d_lastcol[ws], pl->gather ? nullptr : &pl->d_roles->spin_timeout, bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
@@ -947,11 +978,8 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<0>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
                               start, windowed ? nullptr : stop, 0, ba);
-    else if (pl->V <= 32)
-        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<33>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
-                              start, windowed ? nullptr : stop, 0, ba);
     else
-        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<65>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
+        hipExtLaunchKernelGGL(select_strider(pl->VP), dim3(pl->B), dim3(64 * (pl->bt_waves + pl->bt_scorers)), pl->lds_bt, st,
                               start, windowed ? nullptr : stop, 0, ba);
     HIP_TRY(pl->eng, hipGetLastError());
     if (windowed) {

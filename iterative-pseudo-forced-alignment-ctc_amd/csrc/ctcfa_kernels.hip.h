@@ -63,6 +63,7 @@
 #endif
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 namespace ctcfa {
 
@@ -1130,6 +1131,8 @@ struct BtParams {
     int L;            // score_min_mean_over_L
     int rec_bytes;    // bytes reserved for rec[] (multiple of 16) in dynamic LDS
     int lab_bytes;    // checkpoint mode: bytes reserved for the label copy that follows rec[] (multiple of 16), else 0
+    int fol_bytes;    // checkpoint mode: bytes reserved for the LDS copy of frame_of_label (multiple of 16)
+    int scorers;      // checkpoint mode: waves of the workgroup (the last ones) that only score utterances
     double dur;       // index_duration
 };
 
@@ -1183,11 +1186,12 @@ template <int NTHREADS, class Tick = NoTick>
 __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, double dur, const int32_t* ub,
                                                  const int32_t* fol, const float* cps, int T, int C, int U,
                                                  double* __restrict__ seg_start, double* __restrict__ seg_end,
-                                                 double* __restrict__ seg_score, int tid = -1, Tick tick = Tick()) {
+                                                 double* __restrict__ seg_score, int tid = -1, Tick tick = Tick(),
+                                                 int nwaves_rt = 0) {
     if (tid < 0) tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = NTHREADS / 64;
+    const int NW = NTHREADS > 0 ? NTHREADS / 64 : nwaves_rt;   // (NTHREADS == 0: the caller's wave count is a run-time value)
     auto tim = [&](int c) {
         if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
         return (double)__hip_atomic_load(fol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * dur;
@@ -1235,6 +1239,55 @@ __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, doubl
             seg_score[sd.utt_off + u] = min_avg;
         }
         tick();
+    }
+}
+
+// One utterance of determine_utterance_segments() by one wave (lanes = sliding windows); `fol` and `cps` in LDS.
+__device__ __forceinline__ void score_one_utterance(const SegDesc& sd, int L, double dur, const int32_t* ub, const int32_t* fol,
+                                                    const float* cps, int T, int C, int u, double* __restrict__ seg_start,
+                                                    double* __restrict__ seg_end, double* __restrict__ seg_score, int lane) {
+    auto tim = [&](int c) {
+        if (c < 0) c += C;  // NumPy wrap (never taken for well-formed utt_begin)
+        return (double)fol[c] * dur;
+    };
+    const int n = L;
+    const int b = ub[u], e = ub[u + 1];
+    const double mid_b = (tim(b) + tim(b - 1)) / 2;
+    const double sb = tim(b + 1) - 0.5;
+    const double start = (mid_b > sb) ? mid_b : sb;  // max(timings[b+1]-0.5, middle)
+    const double mid_e = (tim(e) + tim(e - 1)) / 2;
+    const double ee = tim(e - 1) + 0.5;
+    const double end = (mid_e < ee) ? mid_e : ee;  // min(timings[e-1]+0.5, middle)
+    const long long start_t = (long long)rint(start / dur);
+    const long long end_t = (long long)rint(end / dur);
+    double min_avg;
+    if (end_t <= start_t) {
+        min_avg = -10000000000.0;
+    } else if (end_t - start_t <= n) {
+        long long lo = start_t < 0 ? 0 : start_t, hi = end_t > T ? T : end_t;
+        if (lo > T) lo = T;
+        if (hi < lo) hi = lo;
+        min_avg = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
+    } else {
+        double local = 0.0;
+        for (long long t0 = start_t + lane; t0 < end_t - n; t0 += 64) {
+            long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
+            if (lo > T) lo = T;
+            if (hi < lo) hi = lo;
+            const double m = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
+            if (m < local) local = m;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(local, off);
+            if (o < local) local = o;
+        }
+        min_avg = local;
+    }
+    if (lane == 0) {
+        seg_start[sd.utt_off + u] = start;
+        seg_end[sd.utt_off + u] = end;
+        seg_score[sd.utt_off + u] = min_avg;
     }
 }
 
@@ -1849,6 +1902,580 @@ backtrack_kernel(BtArgs a) {
     backtrack_body<kBtThreads, PB>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Checkpoint-mode backtrack, round 3: "striders".
+//
+// The fill left table row 32j+32 of every block j (trace word [j][pc]).  The walk from the end cell
+// to (0, 0) is one dependent chain through T rows; everything else a block needs -- its 64-column
+// window of recurrence + residual test -- depends only on WHERE the path enters the block, and the
+// path drops at most one column per row.  So NW waves (blockDim / 64, one 32-row block each,
+// blocks dealt round-robin from the end cell downwards) recompute their block SPECULATIVELY while
+// the walks of the NW-1 blocks above are still going on: the window is anchored on the latest
+// entry column anybody has published, moved down by the columns the path is expected to drop on
+// the way (its recent slope), lane l = column top - l.  Row r of a window is wrong in lanes >= 64-r
+// (their left neighbours lie outside the wave); the path enters at lane x = top - entry and sits in
+// lanes <= x + 31 - r, so any 0 <= x <= 31 is exact.  When the block's true entry column arrives
+// (LDS word written by the wave that walked the block above) and x is outside that range, the
+// block is recomputed from its exact entry column: speculation only ever costs time.
+//   * decisions are the v_cmp masks themselves (one SGPR pair per row, lane = column): the walk is
+//     4 scalar instructions per row (s_bitcmp1_b64 / s_addc_u32), no decision words, no LDS hop
+//     between a "recompute" and a "walker" wave, no workgroup barrier in the loop;
+//   * every wave stages the emission rows of its OWN next block: 32 V floats are contiguous in
+//     lpz -- dwordx4 loads issued a whole turn ahead, written into the wave's private LDS slot (row
+//     pitch P) after the block that used it; the start column's label (e = -inf) reads a column of
+//     -inf kept beside the slots;
+//   * per-frame outputs (char_probs, state, frame_of_label) of a block are written by the wave that
+//     walked it, from the emission rows it still holds in LDS -- lpz is read once per block;
+//   * end-cell argmax before, utterance scoring after (all waves), as in backtrack_kernel.
+// dynamic LDS: rec[nblk] | labels (bytes) | -inf column [32][P] | NW slots [32][P] | char_probs [T]
+// ---------------------------------------------------------------------------------------
+constexpr int kSbMaxWaves = 8;
+constexpr int kSbSentinel = (int)0x80000000;   // rec[j].x: entry column of block j not known yet
+#ifndef CTCFA_SB_MARGIN
+#define CTCFA_SB_MARGIN 15
+#endif
+#ifndef CTCFA_SB_RING
+#define CTCFA_SB_RING 8    // emission rows a strider holds in registers ahead of the row it computes
+#endif
+
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };   // four consecutive floats, dword aligned
+
+template <class F, int... I>
+__device__ __forceinline__ void for_each_row(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);   // rows in order, the row number a compile-time constant
+}
+
+template <int P>   // LDS row pitch of a staged emission block (the vocabulary rounded up: 32 / 40 / 48 / 56 / 64)
+__global__ void __launch_bounds__(64 * kSbMaxWaves, 5)   // <= 96 VGPRs: room beside the 64-register fill tiles of the next batch
+stride_backtrack_kernel(BtArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float red_v[kSbMaxWaves];
+    __shared__ int red_t[kSbMaxWaves];
+    __shared__ int sh_misc[4];   // [0] t_end, [1] bad, [2] a wait gave up, [3] next utterance to score
+#ifdef CTCFA_BT_STAMP
+    __shared__ uint32_t sh_pubtime[256];   // when block j's entry column was published (low word of s_memtime)
+#endif
+    const SegDesc sd = a.segs[blockIdx.x];
+    const BtParams& p = a.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = (blockDim.x >> 6) - p.scorers;   // striders: waves 0 .. NW-1 (the waves after them only score)
+    const int nthreads = blockDim.x;
+    const int ferr = a.fill_err ? *a.fill_err : 0;   // (asked for first: nothing else waits behind it)
+    const int T = sd.T, C = sd.C, U = sd.U, shift = sd.shift, V = p.V;
+    const float* __restrict__ seg_lpz = a.lpz + sd.lpz_off;
+    const int32_t* __restrict__ seg_lab = a.labels + sd.lab_off;
+    const uint32_t* __restrict__ seg_bits = a.bits + sd.bits_off;
+    int32_t* fol = a.frame_of_label + sd.lab_off;
+    float* cp = a.char_prob + sd.frm_off;
+    int32_t* st = a.state ? a.state + sd.frm_off : nullptr;
+    const bool want_seg = (a.utt_begin != nullptr) && (a.seg_score != nullptr) && U > 0;
+#ifdef CTCFA_BT_STAMP   // tuning builds: where a strider's cycles go (tools/bt_stamps.py reads them from the `state` buffer)
+    unsigned long long* stamp_out = st ? reinterpret_cast<unsigned long long*>(a.state + sd.frm_off) : nullptr;
+    st = nullptr;
+    uint32_t sk[16] = {0};   // (low words of s_memtime) [0] start [1] end cell known [2] chain done [3] all done [4] scored; [5..] per-turn sums
+    uint32_t s_last = (uint32_t)__builtin_amdgcn_s_memtime();
+    sk[0] = s_last;
+#define SB_LAP(k) do { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); sk[k] += now_ - s_last; s_last = now_; } while (0)
+#define SB_MARK(k) do { sk[k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#define SB_COUNT(k) do { sk[k] += 1; } while (0)
+#else
+#define SB_LAP(k) do { } while (0)
+#define SB_MARK(k) do { } while (0)
+#define SB_COUNT(k) do { } while (0)
+#endif
+    constexpr int SLOT_BYTES = kRows * P * 4;
+    lds_vint* rec = (lds_vint*)smem;                           // [2j] entry column of block j, [2j+1] its switch mask
+    uint8_t* labs = smem + p.rec_bytes;
+    int32_t* fol_lds = reinterpret_cast<int32_t*>(smem + p.rec_bytes + p.lab_bytes);   // frame_of_label, for the scoring
+    const uint32_t neg_base = (uint32_t)(p.rec_bytes + p.lab_bytes + p.fol_bytes);
+    const uint32_t slot0 = neg_base + SLOT_BYTES;
+    float* cps = reinterpret_cast<float*>(smem + slot0 + NW * SLOT_BYTES);   // char_probs of this segment (scoring)
+
+    auto fail = [&](int code) {
+        for (int c = tid; c < C; c += nthreads) fol[c] = 0;
+        for (int t = tid; t < T; t += nthreads) {
+            cp[t] = 0.0f;
+            if (st) st[t] = -2;
+        }
+        if (want_seg)
+            for (int u = tid; u < U; u += nthreads) {
+                a.seg_start[sd.utt_off + u] = 0.0;
+                a.seg_end[sd.utt_off + u] = 0.0;
+                a.seg_score[sd.utt_off + u] = 0.0;
+            }
+        if (tid == 0) {
+            a.status_out[sd.seg_index] = code;
+            a.t_end_out[sd.seg_index] = -1;
+        }
+    };
+    if (sd.prestatus == kPreWindowed) return;  // windowed_kernel owns this segment
+    if (sd.prestatus != 0) {
+        fail(sd.prestatus);
+        return;
+    }
+    if (ferr) {   // the fill gave up on a progress counter: its trace is not to be trusted
+        fail(5);
+        return;
+    }
+
+    // ---- end cell: first maximum of the last column (lastMax / lastArgMax of the package's fill) ----
+    {
+        const float* lc = a.lastcol + sd.frm_off;
+        float bv = -__builtin_inff();
+        int bt = 0x7fffffff;
+        for (int t = tid; t < T; t += nthreads) {
+            const float v = (t == 0) ? kProbMax : lc[t];  // table[0, C-1] = -1e9
+            if (bt == 0x7fffffff || v > bv) {             // ascending t per thread: strict '>' keeps the first
+                bv = v;
+                bt = t;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int ot = __shfl_xor(bt, off);
+            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
+                bv = ov;
+                bt = ot;
+            }
+        }
+        if (lane == 0) {
+            red_v[wave] = bv;
+            red_t[wave] = bt;
+        }
+    }
+    const int nblk = (T - 1 + kRows - 1) / kRows;
+    for (int j = tid; j < nblk; j += nthreads) {
+        rec[2 * j] = kSbSentinel;
+        rec[2 * j + 1] = 0;
+    }
+    for (int c = tid; c < C; c += nthreads) {
+        fol[c] = 0;
+        fol_lds[c] = 0;
+        labs[c] = (uint8_t)seg_lab[c];  // [0] = -1 is never looked up
+    }
+    for (int i = tid; i < kRows * P; i += nthreads) reinterpret_cast<float*>(smem + neg_base)[i] = -__builtin_inff();
+    if (tid < 4) sh_misc[tid] = (tid == 3) ? U - 1 : 0;   // [3]: the next utterance to score (from the last one down)
+    __threadfence_block();
+    __syncthreads();
+
+    int t_end;
+    {
+        float bv = red_v[0];
+        int bt = red_t[0];
+        for (int q = 1; q < (nthreads >> 6); ++q) {   // (every wave of the workgroup took part, scorers included)
+            const float ov = red_v[q];
+            const int ot = red_t[q];
+            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
+                bv = ov;
+                bt = ot;
+            }
+        }
+        t_end = __builtin_amdgcn_readfirstlane(bt);
+        if (p.flags & 4u) t_end = T - 1;
+    }
+    SB_MARK(1);
+    // frames the path never visits: t = 0 and everything after the end cell
+    for (int t = (t_end >= 1 ? t_end + 1 : 0) + tid; t < T; t += nthreads) {
+        cp[t] = 0.0f;
+        cps[t] = 0.0f;
+        if (st) st[t] = -2;
+    }
+    if (tid == 0 && t_end >= 1) {
+        cp[0] = 0.0f;
+        cps[0] = 0.0f;
+        if (st) st[0] = -2;
+    }
+    if (want_seg) lds_barrier();   // (the scoring may start on these frames while the walk is still on its way)
+
+    const int top0 = C - 1 + shift;   // the end cell's padded column
+    if (t_end >= 1) {
+        const int jstart = (t_end - 1) >> 5;
+        const bool preamble = (p.flags & 2u) != 0;
+        const bool gratis = (p.flags & 1u) != 0;
+        const uint32_t my_slot = slot0 + (uint32_t)(wave * SLOT_BYTES);
+        if (tid == 0) rec[2 * jstart] = top0;
+        if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+
+        // ---- staging: the 32 V floats of block jb are contiguous in lpz ----
+        constexpr int NQ = kRows * P / 256;   // dwordx4 loads per lane that cover a block
+        const int elems = kRows * V;
+        const uint32_t magicV = ((1u << 20) + (uint32_t)V - 1u) / (uint32_t)V;   // n / V == (n * magicV) >> 20 for n < 4096
+        float4 stg[NQ];
+        int stg_n0 = 0;   // first element (of the segment's lpz) of the block in stg[]
+        const int nmax = T * V - 4 > 0 ? T * V - 4 : 0;   // last place a dwordx4 load may start
+        auto issue = [&](int jb) {
+            const int n0 = (jb * kRows + 1) * V;
+            stg_n0 = n0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                int n = n0 + 4 * (lane + 64 * q);
+                n = n < nmax ? n : nmax;   // past the end of the segment: its last four entries again (put() sorts them out)
+                const F4U v = *reinterpret_cast<const F4U*>(seg_lpz + n);
+                stg[q] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        };
+        auto put = [&]() {
+            if (V == P) {
+                // (rows past the end of the segment hold its last entries: nobody reads what becomes of them)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4*>(smem + my_slot + (uint32_t)((lane + 64 * q) * 16)) = stg[q];
+            } else {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));   // (keeps the 4 NQ element addresses out of registers between turns)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    // a load that was moved back to nmax holds element n + k at component k + (n - nmax): matters when
+                    // the vocabulary is not a multiple of four and a block's last valid row ends inside a quad
+                    const int over = stg_n0 + 4 * (ln + 64 * q) - nmax;
+                    const int sh = over > 0 ? over : 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int src = k + sh;
+                        const float val = src == 0 ? stg[q].x : src == 1 ? stg[q].y : src == 2 ? stg[q].z : stg[q].w;
+                        const uint32_t m = (uint32_t)(4 * (ln + 64 * q) + k);
+                        const uint32_t row = (m * magicV) >> 20;
+                        const uint32_t cv = m - row * (uint32_t)V;
+                        // elements past the block (a pitch wider than the vocabulary): parked on the -inf column's last row, entry 1
+                        const uint32_t ad = (int)m < elems ? my_slot + (row * P + cv) * 4u : neg_base + (uint32_t)(((kRows - 1) * P + 1) * 4);
+                        *reinterpret_cast<float*>(smem + ad) = val;
+                    }
+                }
+            }
+        };
+
+        // ---- one block: recurrence + residual test over the 64 columns below `top` ----
+        // The walk is composed while the rows are computed, for EVERY lane the path might enter the block in:
+        // after row k, Sv[l] holds the SWITCH bits (row 31 - b at bit b) of the path that is in lane l at row k,
+        // down to the block's first row -- Sv_k[l] = switch(k, l) ? (Sv_{k-1} | bit k)[l + 1] : Sv_{k-1}[l], one v_or and
+        // one v_cndmask with a wave_shl:1 DPP source per row.  When the block's true entry lane x arrives, the walk
+        // of the block is one v_readlane (the path leaves in lane x + popcount): nothing of it is left on the chain
+        // from block to block.
+        auto recompute = [&](int j, int top, int ilast, uint32_t& Sout) {
+            const int col = top - lane;
+            const int c = col - shift;
+            const bool pseudo = c <= 0;                    // start column and left of it: e = -inf
+            const uint32_t widx = (j >= 1 && col >= 0) ? (uint32_t)((j - 1) * p.Cpad + col) : 0u;
+            float prev = __uint_as_float(seg_bits[widx]);  // table row 32 j (issued first: the LDS reads below hide part of it)
+            const int lab = pseudo ? 0 : (int)labs[c];     // c <= C-1: the path never sits right of the end cell's column
+            const bool pp = pseudo && preamble;
+            const uint32_t ea = pseudo ? neg_base : my_slot + (uint32_t)lab * 4u;
+            const uint32_t la = pp ? neg_base : my_slot + (uint32_t)p.blank * 4u;
+            const float flo = pp ? 0.0f : kProbMax;        // the start column stays for free under preamble_transition_cost_zero
+            // emission operands: a ring of RH rows in registers, row i + RH requested while row i is computed
+            constexpr int RH = CTCFA_SB_RING;
+            float e[RH], lb[RH];
+#pragma unroll
+            for (int i = 0; i < RH; ++i) {
+                e[i] = *reinterpret_cast<const float*>(smem + ea + i * (P * 4));
+                lb[i] = *reinterpret_cast<const float*>(smem + la + i * (P * 4));
+            }
+            if (j == 0) prev = pseudo ? 0.0f : kProbMax;   // table row 0
+            else if (col < 0) prev = 0.0f;                 // left of the padded table (feeds nothing that is read)
+            // m: the stay step the package's BACKTRACK assumes (max(blank, label)); mf: the one the FILL charged
+            // -- 0 in a column labelled blank under blank_transition_cost_zero, else m
+            const bool free_stay = gratis && !pseudo && lab == p.blank;
+            uint32_t Sv = 0u;
+            auto rows = [&](auto gratis_tag, auto first_tag) {
+                auto row = [&](auto row_tag) {
+                    constexpr int i = decltype(row_tag)::value;   // (a constant the asm below can take as a literal)
+                    if (decltype(first_tag)::value && i > ilast) return;   // the end cell's block: rows after it are not part of the path
+                    const float ei = e[i % RH], li = lb[i % RH];
+                    if (i % 2 == 1 && i + RH < kRows) {   // rows i - 1 and i are consumed: their ring entries take rows i + RH - 1, i + RH (one ds_read2_b32)
+#pragma unroll
+                        for (int r = i + RH - 1; r <= i + RH; ++r) {
+                            e[r % RH] = *reinterpret_cast<const float*>(smem + ea + r * (P * 4));
+                            lb[r % RH] = *reinterpret_cast<const float*>(smem + la + r * (P * 4));
+                        }
+                    }
+                    const float m = max3f(li, ei, flo);
+                    const float mf = (decltype(gratis_tag)::value && free_stay) ? 0.0f : m;
+                    const float pl = dpp_wave_shl1(prev);
+                    const float aa = pl + ei;
+                    const float bb = prev + mf;
+                    const float nw = max3f(aa, bb, kProbMax);
+                    const float rsw = ei - (nw - pl);
+                    const float rst = m - (nw - prev);
+                    // SWITCH iff |rst| > |rsw| (ties and NaNs stay; a start-column lane has |rsw| = inf: it always stays).
+                    // vcc = STAY; Sv = stay ? Sv : (Sv | bit)[l + 1] -- the lane shift rides on the v_cndmask as a DPP source
+                    // modifier (the compiler emits a separate v_mov_dpp instead).  Wait states gfx950 wants and nobody
+                    // inserts inside an asm statement: a VALU that reads VCC two after the VALU that wrote it; a DPP
+                    // source two after its last VALU write (U) -- the v_or and the s_nop 1 stand in both gaps.
+                    uint32_t U;
+                    asm volatile(
+                        "v_cmp_ngt_f32_e64 vcc, |%2|, |%3|\n\t"
+                        "v_or_b32 %1, %4, %0\n\t"
+                        "s_nop 1\n\t"
+                        "v_cndmask_b32_dpp %0, %1, %0, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                        : "+v"(Sv), "=&v"(U)
+                        : "v"(rst), "v"(rsw), "i"(1u << (31 - i))
+                        : "vcc");
+                    prev = nw;
+                };
+                for_each_row(row, std::make_integer_sequence<int, kRows>{});
+            };
+            if (ilast < kRows - 1) {
+                if (gratis) rows(std::true_type{}, std::true_type{});
+                else rows(std::false_type{}, std::true_type{});
+            } else {
+                if (gratis) rows(std::true_type{}, std::false_type{});
+                else rows(std::false_type{}, std::false_type{});
+            }
+            Sout = Sv;
+        };
+
+        int j = wave < NW ? jstart - wave : -1;
+        if (j >= 0) {
+            issue(j);
+            put();
+        }
+        int spin_fail = 0;
+#ifdef CTCFA_BT_STAMP
+        s_last = (uint32_t)__builtin_amdgcn_s_memtime();
+        sk[5] = s_last - sk[1];   // pre-loop + first block's rows from HBM
+#endif
+        for (; j >= 0; j -= NW) {
+            SB_COUNT(13);
+            if (j - NW >= 0) issue(j - NW);   // my next block's rows: a whole turn in flight
+            // ---- anchor: the nearest block above whose entry column is known ----
+            int top, d, top_anchor = 0;
+            {
+                int spins = 0;
+                unsigned long long known;
+                int val;
+                do {
+                    const int jj = j + lane;
+                    val = (lane < NW && jj <= jstart) ? (int)rec[2 * jj] : kSbSentinel;
+                    known = __builtin_amdgcn_ballot_w64(val != kSbSentinel);
+                    if (known == 0ull) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kSpinCap) break;
+                    }
+                } while (known == 0ull);
+                if (known == 0ull) {   // (cannot happen: my own last walk, or the kernel start, published one)
+                    spin_fail = 1;
+                    d = 0;
+                    top = 0;
+                } else {
+                    d = __builtin_ctzll(known);
+                    const int E = __builtin_amdgcn_readlane(val, d);
+                    top = E;
+                    top_anchor = E > top0 ? top0 : E;
+                    if (d > 0) {
+                        // columns the path is expected to drop over the d blocks in between: the mean of its slope over
+                        // the last blocks walked (up to 8) and the slope that takes it from here to the first frame
+                        const int jj = j + d;
+                        int hist = jstart - jj;
+                        hist = hist > 8 ? 8 : hist;
+                        const float togo = (float)(E - shift) * 256.0f * __builtin_amdgcn_rcpf((float)(jj + 1));
+                        int drop_q8 = __builtin_amdgcn_readfirstlane((int)togo);
+                        if (hist >= 2) {
+                            const int Eh = (int)rec[2 * (jj + hist)];
+                            const int local_q8 = (int)((float)(Eh - E) * 256.0f * __builtin_amdgcn_rcpf((float)hist));
+                            drop_q8 = (drop_q8 + __builtin_amdgcn_readfirstlane(local_q8)) >> 1;
+                        }
+                        const int pd = (drop_q8 * d) >> 8;
+                        const int lift = pd - CTCFA_SB_MARGIN;
+                        if (lift > 0) top = E - lift;
+                    }
+                }
+                // (whatever the words in LDS say, no window starts outside the padded table: every global address
+                // below is derived from `top`)
+                top = top < 0 ? 0 : (top > top0 ? top0 : top);
+            }
+            // ---- windows.  A wave that has recomputed its window and still has no entry column does not sit and
+            // poll: it recomputes the window NEXT to it (32 columns further down, then 32 further up) -- every
+            // window kept is one VGPR (Sv) and one SGPR (its top), and the path may then enter anywhere in 64 or
+            // 96 columns around the prediction.  The time would have been spent waiting; what a miss costs is a
+            // whole recompute on the chain from block to block.
+            constexpr int kCand = 3;
+            int ctop[kCand];
+            uint32_t cS[kCand];
+            int ncand = 0;
+            uint32_t Svv = 0u;
+            int x = 0;
+            const int ilast = (j == jstart) ? ((t_end - 1) & 31) : kRows - 1;
+            const int anchorE = top_anchor;
+            const bool in_start_column = anchorE - shift <= 0;   // the path has reached column 0: it stays there, frame by frame
+            SB_LAP(6);    // anchor
+            if (in_start_column) {
+                top = anchorE;   // == this block's entry column: no recurrence to run, no SWITCH to find
+                d = 0;
+            } else {
+                int next_top = top;
+                for (;;) {
+                    uint32_t Snew;
+                    recompute(j, next_top, ilast, Snew);
+                    asm volatile("" :: "v"(Snew));
+                    SB_LAP(7);    // recompute
+                    if (d == 0) {   // exact window
+                        top = next_top;
+                        Svv = Snew;
+                        x = 0;
+                        break;
+                    }
+                    ctop[ncand < kCand ? ncand : kCand - 1] = next_top;
+                    cS[ncand < kCand ? ncand : kCand - 1] = Snew;
+                    if (ncand < kCand) ++ncand;
+                    // the block's true entry column (published by the wave that walked block j + 1)
+                    int ent = __builtin_amdgcn_readfirstlane((int)rec[2 * j]);
+                    int spins = 0;
+                    if (ent == kSbSentinel && ncand < kCand) {
+                        // not there yet: another window meanwhile (below the first one, then above it)
+                        int cand = ncand == 1 ? ctop[0] - kRows : ctop[0] + kRows;
+                        cand = cand < 0 ? 0 : (cand > anchorE ? anchorE : cand);
+                        bool fresh = true;
+#pragma unroll
+                        for (int k = 0; k < kCand; ++k) fresh = fresh && !(k < ncand && ctop[k] == cand);
+                        if (fresh) {
+                            next_top = cand;
+                            SB_COUNT(12);
+                            continue;
+                        }
+                    }
+                    while (ent == kSbSentinel) {
+                        ent = __builtin_amdgcn_readfirstlane((int)rec[2 * j]);
+                        if (++spins > kSpinCap) {
+                            spin_fail = 1;
+                            ent = ctop[0];
+                            break;
+                        }
+                    }
+                    ent = ent > top0 ? top0 : ent;
+                    SB_LAP(8);    // waiting for the block's entry column
+                    bool hit = false;
+#pragma unroll
+                    for (int k = 0; k < kCand; ++k) {
+                        const int xk = ctop[k < ncand ? k : 0] - ent;
+                        if (!hit && k < ncand && xk >= 0 && xk < kRows) {
+                            hit = true;
+                            top = ctop[k];
+                            Svv = cS[k];
+                            x = xk;
+                        }
+                    }
+                    if (hit) break;
+                    SB_COUNT(14);
+                    next_top = ent < 0 ? 0 : ent;   // the path entered outside every window: once more, from the exact entry column
+                    d = 0;
+                }
+            }
+            // ---- the walk of this block: look up the entry lane ----
+            const uint32_t S = in_start_column ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)Svv, x);
+            const int pos = x + __builtin_popcount(S);   // one lane down per SWITCH
+            SB_LAP(9);    // walk
+            const int entry = top - x;          // padded column in which the path enters block j (at its last row)
+            const int leave = top - pos;        // ... and the one it is in when it reaches row 32 j
+#ifdef CTCFA_BT_STAMP
+            if (lane == 0 && j >= 1) ((volatile uint32_t*)sh_pubtime)[(j - 1) & 255] = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+            if (lane == 0) {
+                if (j >= 1) rec[2 * (j - 1)] = leave;   // first: the next walk waits for this word
+                else {
+                    sh_misc[0] = t_end;
+                    sh_misc[1] = (leave - shift > 0);   // reached t == 0 in a label column: the package's IndexError
+                }
+            }
+            // ---- per-frame outputs of this block, lanes = rows, from the emission rows still in my slot ----
+            if (lane < kRows) {
+                const int i = lane;
+                const int t = j * kRows + 1 + i;
+                if (t <= t_end) {
+                    const int b = 31 - i;
+                    const int pct = entry - __builtin_popcount(S & ((1u << b) - 1u));
+                    const int sw = (S >> b) & 1u;
+                    const int c = pct - shift;
+                    const float lbv = *reinterpret_cast<const float*>(smem + my_slot + (uint32_t)((i * P + p.blank) * 4));
+                    float prob;
+                    int s_lab = -1;
+                    if (c <= 0) {
+                        prob = __builtin_fmaxf(lbv, kMaxProb);
+                    } else {
+                        const int g = (int)labs[c];
+                        const float ev = *reinterpret_cast<const float*>(smem + my_slot + (uint32_t)((i * P + g) * 4));
+                        const float mx = __builtin_fmaxf(ev, kMaxProb);
+                        if (sw) {
+                            prob = mx;
+                            s_lab = g;
+                            fol[c] = t;
+                            fol_lds[c] = t;
+                        } else {
+                            prob = (mx > lbv) ? mx : lbv;
+                        }
+                    }
+                    cp[t] = prob;
+                    cps[t] = prob;
+                    if (st) st[t] = s_lab;
+                }
+            }
+            if (lane == 0) rec[2 * j + 1] = 1;   // this block's frames are out (LDS executes a wave's operations in order)
+            SB_LAP(10);   // publish + per-frame outputs
+            if (j - NW >= 0) put();   // (waits for the loads issued at the top of this turn)
+            SB_LAP(11);   // slot refill
+        }
+        SB_MARK(2);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- determine_utterance_segments, from the last utterance down, by whichever wave has nothing else to do
+        // (the scorer waves from the start, a strider once its blocks are walked).  Utterance u is ready when every
+        // block from the one in which the path entered the column before its first label upwards has its frames out.
+        if (want_seg) {
+            const int32_t* ub = a.utt_begin + sd.utt_off + sd.seg_index;
+            int jdone = jstart + 1;   // blocks jdone .. jstart are out
+            for (;;) {
+                int u = 0;
+                if (lane == 0) u = __hip_atomic_fetch_add(&sh_misc[3], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                u = __builtin_amdgcn_readfirstlane(u);
+                if (u < 0) break;
+                const int cneed = ub[u] - 1;
+                for (int spins = 0;; ++spins) {
+                    while (jdone > 0 && __builtin_amdgcn_readfirstlane((int)rec[2 * (jdone - 1) + 1]) != 0) --jdone;
+                    if (jdone == 0) break;
+                    const int tf = cneed >= 1 ? __builtin_amdgcn_readfirstlane(((volatile int32_t*)fol_lds)[cneed]) : 0;
+                    if (tf > 0 && ((tf - 1) >> 5) >= jdone) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (spins > kSpinCap) {
+                        spin_fail = 1;
+                        break;
+                    }
+                }
+                score_one_utterance(sd, p.L, p.dur, ub, fol_lds, cps, T, C, u, a.seg_start, a.seg_end, a.seg_score, lane);
+            }
+        }
+        if (spin_fail && lane == 0) sh_misc[2] = 1;
+    } else {
+        if (tid == 0) {
+            sh_misc[0] = t_end;
+            sh_misc[1] = 1;   // t_end == 0 with C >= 2 label columns: the package's IndexError
+        }
+        // (no path: the backtrack fails below, nothing to score)
+    }
+    __threadfence_block();
+    __syncthreads();
+    SB_MARK(3);
+    if (sh_misc[2]) {
+        fail(5);
+        return;
+    }
+    if (sh_misc[1]) {
+        fail(2);
+        return;
+    }
+    if (tid == 0) {
+        a.status_out[sd.seg_index] = 0;
+        a.t_end_out[sd.seg_index] = t_end;
+    }
+#ifdef CTCFA_BT_STAMP
+    SB_MARK(4);
+    if (stamp_out && lane == 0 && T * 4 >= kSbMaxWaves * 16 * 8)
+        for (int k = 0; k < 16; ++k) stamp_out[wave * 16 + k] = k >= 1 && k <= 4 ? (unsigned long long)(sk[k] - sk[0]) : (unsigned long long)sk[k];
+#endif
+}
+#undef SB_LAP
+#undef SB_MARK
+#undef SB_COUNT
 
 // ---------------------------------------------------------------------------------------
 // Windowed regime (T > min_window_size): ctc-segmentation keeps only W = min(window, T) rows
