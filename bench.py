@@ -492,7 +492,10 @@ def main():
         # the path's only exchange: gather the final segment boundaries (the role of
         # merge_aligned_files.py:17-25), on its own stream so it overlaps later steps
         buf = seg_ring[g % 3]
-        comm.wait_stream(stream)
+        if pipelined:
+            plan.flush(comm.cuda_stream)   # the backtracks run on the plan's own stream: comm waits for every one enqueued so far
+        else:
+            comm.wait_stream(stream)
         with torch.cuda.stream(comm):
             if rehearsal:   # gloo has no all_gather_into_tensor for device tensors
                 parts = [torch.empty_like(buf) for _ in range(world)]
@@ -513,10 +516,8 @@ def main():
                         sg[2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(),
                         stream.cuda_stream, pipelined=pipelined)
         if do_gather:
-            # serial: step i is complete on `stream` as soon as it is enqueued; pipelined: step i-2 is
-            done = i if not pipelined else i - 2
-            if done >= 0 and done % G == G - 1:
-                gather(done // G)
+            if i % G == G - 1:
+                gather(i // G)
 
     def drain():
         if pipelined:

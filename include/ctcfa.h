@@ -132,10 +132,11 @@ int ctcfa_plan_run_device(ctcfa_plan* plan, const float* d_lpz, const int32_t* d
  * Pipelined variant for back-to-back batches: the fill kernel of this call is enqueued on
  * `stream`, the backtrack kernel on a stream the plan owns, so that the (latency-bound,
  * one-workgroup-per-segment) backtrack of call k overlaps the fill of call k+1.  The plan
- * alternates between two workspaces.  Outputs of call k are complete on `stream` only
- * after the NEXT-BUT-ONE pipelined call or after ctcfa_plan_flush(plan, stream), which makes
- * `stream` wait for every outstanding backtrack; give consecutive calls different output
- * buffers.  Same arguments as ctcfa_plan_run_device.
+ * rotates through four workspaces; a call whose workspace is still being read (the caller is four
+ * runs ahead of the GPU) waits for that backtrack ON THE HOST -- nothing but fill kernels ever
+ * enters `stream`.  Outputs of a call are complete on `stream` only after
+ * ctcfa_plan_flush(plan, stream), which makes `stream` wait for every outstanding backtrack;
+ * give consecutive calls different output buffers.  Same arguments as ctcfa_plan_run_device.
  */
 int ctcfa_plan_run_pipelined(ctcfa_plan* plan, const float* d_lpz, const int32_t* d_labels,
                              const int32_t* d_utt_begin, int32_t* d_frame_of_label,

@@ -47,6 +47,12 @@ struct ctcfa_engine {
     int64_t trace_calls = 0;
 };
 
+// Workspaces (trace words + last-column scores) a plan rotates through in the pipelined entry.  Two would do for
+// "backtrack(k) beside fill(k+1)"; with four, the backtrack that last read the workspace of run k is that of run
+// k - 4, long finished -- the HOST can see that (or wait for it) and no wait has to sit in the GPU queue between
+// two fills (such a packet, satisfied or not, cost config 3 12 us per step).
+constexpr int kWorkspaces = 4;
+
 struct ctcfa_plan {
     ctcfa_engine* eng = nullptr;
     ctcfa_params prm{};
@@ -61,15 +67,15 @@ struct ctcfa_plan {
     int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
     SegDesc* d_segs = nullptr;
     bool scratch_owned = false;  // d_segs / d_roles / d_bits[0] / d_lastcol[0] live in the engine's scratch
-    // workspace [2]: index 1 exists only once the pipelined entry has been used
-    uint32_t* d_bits[2] = {nullptr, nullptr};
-    float* d_lastcol[2] = {nullptr, nullptr};
+    // workspaces: index 0 always; the others exist once the pipelined entry has been used
+    uint32_t* d_bits[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
+    float* d_lastcol[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
     // pipelined mode: backtrack of run k on `side` overlaps the fill of run k+1 on the caller's stream
     hipStream_t side = nullptr;
-    hipEvent_t ev_fill_done[2] = {nullptr, nullptr};
-    hipEvent_t ev_bt_done[2] = {nullptr, nullptr};
-    bool bt_pending[2] = {false, false};
-    hipEvent_t bt_done_ev[2] = {nullptr, nullptr};  // the event that marks workspace q free again
+    hipEvent_t ev_fill_done[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_bt_done[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
+    bool bt_pending[kWorkspaces] = {false, false, false, false};
+    hipEvent_t bt_done_ev[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};  // the event that marks workspace q free again
     int64_t pipe_runs = 0;
     // event ring: 4 events per recorded run (fill start/end, backtrack start/end)
     std::vector<hipEvent_t> ev;
@@ -433,7 +439,7 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
     if (plan->d_win_list) (void)hipFree(plan->d_win_list);
     if (plan->d_win_table) (void)hipFree(plan->d_win_table);
     if (plan->d_win_offs) (void)hipFree(plan->d_win_offs);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kWorkspaces; ++q) {
         if (plan->d_bits[q]) (void)hipFree(plan->d_bits[q]);
         if (plan->d_lastcol[q]) (void)hipFree(plan->d_lastcol[q]);
         if (plan->ev_fill_done[q]) (void)hipEventDestroy(plan->ev_fill_done[q]);
@@ -889,11 +895,11 @@ int ctcfa_plan_set_timing_stride(ctcfa_plan* pl, int stride) {
 int ctcfa_plan_set_timing(ctcfa_plan* pl, int slots) {
     if (!pl || slots < 0 || slots > 4096) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
-    if (slots > 0 && slots < 4) slots = 4;  // the pipelined entry waits on the event of run k-2
-    if (pl->side && (pl->bt_pending[0] || pl->bt_pending[1])) {
+    if (slots > 0 && slots < 2 * kWorkspaces) slots = 2 * kWorkspaces;  // the pipelined entry looks at the event of run k - kWorkspaces
+    if (pl->side) {
         // a pending hand-over may be one of the timing events about to be destroyed
         HIP_TRY(eng, hipStreamSynchronize(pl->side));
-        pl->bt_pending[0] = pl->bt_pending[1] = false;
+        for (int q = 0; q < kWorkspaces; ++q) pl->bt_pending[q] = false;
     }
     for (auto& e : pl->ev)
         if (e) (void)hipEventDestroy(e);
@@ -952,7 +958,7 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
 }
 
 int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hipStream_t st,
-                     hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+                     hipEvent_t start = nullptr, hipEvent_t stop = nullptr, bool beside_fill = false) {
 #ifdef CTCFA_STAMP
     return CTCFA_OK;   // (the stamps sit where the backtrack would write)
 #endif
@@ -971,6 +977,12 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.lab_bytes = pl->lab_bytes;
     bp.fol_bytes = pl->fol_bytes;
     bp.scorers = pl->ckpt ? pl->bt_scorers : 0;
+    // Beside the fill of the next batch the striders run below the fill's tiles (config 3: 0.174 -> 0.165 ms per
+    // step; a tile that loses an issue slot holds up every tile to its right), alone at the top.
+    bp.prio = beside_fill ? 0 : 3;
+    if (const char* e = std::getenv("CTCFA_SB_PRIO")) bp.prio = std::max(0, std::min(3, std::atoi(e)));
+    bp.windows = 2;
+    if (const char* e = std::getenv("CTCFA_SB_WINDOWS")) bp.windows = std::max(1, std::min(3, std::atoi(e)));
     bp.dur = pl->prm.index_duration;
     const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
                            pl->d_lastcol[ws], pl->gather ? nullptr : &pl->d_roles->spin_timeout, bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
@@ -1045,32 +1057,34 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     if (rc != CTCFA_OK) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     DeviceGuard on_device(eng->device);
-    if (!pl->side) {  // first use: second workspace, side stream, hand-over events
-        HIP_TRY(eng, hipMalloc(&pl->d_bits[1], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
-        HIP_TRY(eng, hipMalloc(&pl->d_lastcol[1], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
-        for (int q = 0; q < 2; ++q) {
-            HIP_TRY(eng, hipEventCreate(&pl->ev_fill_done[q]));  // (kernel-attached events carry timestamps)
-            HIP_TRY(eng, hipEventCreate(&pl->ev_bt_done[q]));
+    if (!pl->side) {  // first use: the other workspaces, side stream, hand-over events
+        for (int w = 1; w < kWorkspaces; ++w) {
+            HIP_TRY(eng, hipMalloc(&pl->d_bits[w], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
+            HIP_TRY(eng, hipMalloc(&pl->d_lastcol[w], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+        }
+        for (int w = 0; w < kWorkspaces; ++w) {
+            HIP_TRY(eng, hipEventCreate(&pl->ev_fill_done[w]));  // (kernel-attached events carry timestamps)
+            HIP_TRY(eng, hipEventCreate(&pl->ev_bt_done[w]));
         }
         HIP_TRY(eng, hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
     }
-    const int q = (int)(pl->pipe_runs & 1);
-    // workspace q was last read by the backtrack of run k-2
-    // (asked on the host first: the backtrack of run k-2 is normally long done, and a wait that is
-    // already satisfied still costs the queue a packet between two fill kernels)
-    if (pl->bt_pending[q] && hipEventQuery(pl->bt_done_ev[q]) != hipSuccess)
-        HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
-    // With timing on, the "end" timing events double as the hand-over events: every event record
-    // is a packet the queue has to retire between two kernels.  (The ring has >= 4 slots, so the
-    // event of run k is still untouched when run k+2 waits on it.)
-    const bool timed = pl->ev_slots >= 4 && (pl->run_counter++ % pl->ev_stride == 0);
+    const int q = (int)(pl->pipe_runs % kWorkspaces);
+    // Workspace q was last read by the backtrack of run k - kWorkspaces.  Back-pressure on the HOST: if that
+    // backtrack is not finished, this call waits for it here (the caller is then a full rotation of runs ahead of
+    // the GPU); the queue the fills run in never sees a wait between two of them.
+    if (pl->bt_pending[q]) {
+        if (hipEventQuery(pl->bt_done_ev[q]) != hipSuccess) HIP_TRY(eng, hipEventSynchronize(pl->bt_done_ev[q]));
+        (void)hipGetLastError();   // (a "not ready" from the query is no error)
+        pl->bt_pending[q] = false;
+    }
+    const bool timed = pl->ev_slots >= 2 * kWorkspaces && (pl->run_counter++ % pl->ev_stride == 0);
     hipEvent_t* ev = timed ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
     // the events ride on the kernels' own dispatch packets: nothing else enters the queues
     hipEvent_t fill_done = ev ? ev[1] : pl->ev_fill_done[q];
     if ((rc = launch_fill(pl, a, q, st, ev ? ev[0] : nullptr, fill_done)) != CTCFA_OK) return rc;
     HIP_TRY(eng, hipStreamWaitEvent(pl->side, fill_done, 0));
     hipEvent_t bt_done = ev ? ev[3] : pl->ev_bt_done[q];
-    if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side, ev ? ev[2] : nullptr, bt_done)) != CTCFA_OK) return rc;
+    if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side, ev ? ev[2] : nullptr, bt_done, true)) != CTCFA_OK) return rc;
     if (ev) pl->ev_runs++;
     pl->bt_done_ev[q] = bt_done;
     pl->bt_pending[q] = true;
@@ -1082,7 +1096,7 @@ int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
     if (!pl) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < kWorkspaces; ++q)
         if (pl->bt_pending[q]) {
             HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
             pl->bt_pending[q] = false;

@@ -61,6 +61,16 @@
 #ifndef CTCFA_PF
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
 #endif
+// Trace words are written once and read by another kernel (another XCD, as likely as not): stored past the L2
+// (nt), they leave no dirty lines for the end-of-kernel write-back to find between two fills.
+#ifndef CTCFA_TRACE_NT
+#define CTCFA_TRACE_NT 1
+#endif
+#if CTCFA_TRACE_NT
+#define CTCFA_TRACE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define CTCFA_TRACE_STORE(ptr, val) (*(ptr) = (val))
+#endif
 #include <stdint.h>
 #include <type_traits>
 #include <utility>
@@ -895,7 +905,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         if (lane >= HL) {
             uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
 #pragma unroll
-            for (int k = 0; k < K; ++k) bp[k] = CK ? __float_as_uint(prev[k]) : dec[k];
+            for (int k = 0; k < K; ++k) CTCFA_TRACE_STORE(bp + k, CK ? __float_as_uint(prev[k]) : dec[k]);
         }
         if constexpr (OWNER == 1) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
             const int t = j * kRows + lane;
@@ -936,7 +946,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     if (lane >= HL) {
                         uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
 #pragma unroll
-                        for (int k = 0; k < K; ++k) bp[k] = __float_as_uint(kProbMax);
+                        for (int k = 0; k < K; ++k) CTCFA_TRACE_STORE(bp + k, __float_as_uint(kProbMax));
                     }
                 }
                 if (lane == 63) flags[w] = kGroups * (j + 1);   // (its exchange rows are still the initial -1e9)
@@ -1133,6 +1143,8 @@ struct BtParams {
     int lab_bytes;    // checkpoint mode: bytes reserved for the label copy that follows rec[] (multiple of 16), else 0
     int fol_bytes;    // checkpoint mode: bytes reserved for the LDS copy of frame_of_label (multiple of 16)
     int scorers;      // checkpoint mode: waves of the workgroup (the last ones) that only score utterances
+    int prio;         // checkpoint mode: s_setprio of the striders (0..3)
+    int windows;      // checkpoint mode: windows a strider may recompute for one block while it waits for the entry column (1..3)
     double dur;       // index_duration
 };
 
@@ -2098,7 +2110,13 @@ stride_backtrack_kernel(BtArgs a) {
         const bool gratis = (p.flags & 1u) != 0;
         const uint32_t my_slot = slot0 + (uint32_t)(wave * SLOT_BYTES);
         if (tid == 0) rec[2 * jstart] = top0;
-        if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+        if (wave < NW) {   // (the scoring stays at priority 0)
+            const int pr = (p.flags & kBtFlagLowPriority) ? 0 : p.prio;
+            if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- staging: the 32 V floats of block jb are contiguous in lpz ----
         constexpr int NQ = kRows * P / 256;   // dwordx4 loads per lane that cover a block
@@ -2323,7 +2341,7 @@ stride_backtrack_kernel(BtArgs a) {
                     // the block's true entry column (published by the wave that walked block j + 1)
                     int ent = __builtin_amdgcn_readfirstlane((int)rec[2 * j]);
                     int spins = 0;
-                    if (ent == kSbSentinel && ncand < kCand) {
+                    if (ent == kSbSentinel && ncand < kCand && ncand < p.windows) {
                         // not there yet: another window meanwhile (below the first one, then above it)
                         int cand = ncand == 1 ? ctop[0] - kRows : ctop[0] + kRows;
                         cand = cand < 0 ? 0 : (cand > anchorE ? anchorE : cand);
