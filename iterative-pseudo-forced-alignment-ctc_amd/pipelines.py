@@ -97,7 +97,7 @@ def _write_tsv_atomic(path, rows, columns):
 
 
 def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params, opener=WavFile,
-                          rank=0, world=1, files_per_round=8, speculate=1):
+                          rank=0, world=1, files_per_round=32, speculate=1, batch_lpz=False, frames_fn=None):
     """File loop of iterative_utterance_alignment.main (:436-475), ``files_per_round`` files in
     lockstep.  Returns the list of result TSV paths written by this rank.
 
@@ -106,7 +106,9 @@ def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params
     reference (:440-443) -- an empty one is what a killed run of the reference leaves behind
     (align_utterances.sh:105-107 deletes those) and is redone.  One failing file costs that file:
     the round it was in is repeated file by file and the error is reported at the end.
-    ``speculate``: texts computed ahead with every DP request (``anchor.run_batched``; same results)."""
+    ``speculate``: texts computed ahead with every DP request (``anchor.run_batched``; same results).
+    ``batch_lpz``: the windows of a round share one padded encoder forward (``get_lpz_batch``: see its
+    note on numerics; off by default, as the reference encodes every window alone, :201)."""
     from . import sharding
     samples_to_frames_ratio = aligner.estimate_samples_to_frames_ratio()
     paths = list(dict.fromkeys(df["Sample_Path"].tolist()))
@@ -136,7 +138,8 @@ def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params
     for k in range(0, len(todo), files_per_round):
         group = todo[k:k + files_per_round]
         try:
-            results = anchor.run_batched([coroutine_for(p) for p, _ in group], aligner, speculate=speculate)
+            results = anchor.run_batched([coroutine_for(p) for p, _ in group], aligner, speculate=speculate,
+                                         batch_lpz=batch_lpz, frames_fn=frames_fn)
             for (audio_path, out), result in zip(group, results):
                 finish(audio_path, out, result)
         except Exception as exc:   # which file it was is not known in a lockstep round: redo it file by file
@@ -145,13 +148,80 @@ def align_utterance_files(asr_model, aligner, df, vad_df, dst, logs_path, params
                 if out in written:
                     continue
                 try:
-                    finish(audio_path, out, anchor.run_batched([coroutine_for(audio_path)], aligner, speculate=speculate)[0])
+                    finish(audio_path, out, anchor.run_batched([coroutine_for(audio_path)], aligner, speculate=speculate,
+                                                               batch_lpz=batch_lpz, frames_fn=frames_fn)[0])
                 except Exception as one:
                     print("File {0} could not be aligned ({1}: {2}).".format(audio_path, type(one).__name__, one))
                     failed.append((audio_path, one))
     if failed:
         print("{0} file(s) failed on rank {1}: {2}".format(len(failed), rank, [p for p, _ in failed]))
     return written
+
+
+def _utterance_vocabularies(df, params):
+    """What a fixed-width result record refers to by number: audio files, channels, speakers, databases and
+    every utterance text the rows can yield -- computed from the input table, identically on every rank."""
+    def ids(values):
+        return {str(v): k for k, v in enumerate(dict.fromkeys(values))}
+    texts = []
+    for t in df["Transcription"].tolist():
+        u = text_prep.utterances_for_row(str(t).upper(), max_words_sequence=params.max_words_sequence)
+        texts.extend([u] if isinstance(u, str) else list(u))
+    return {"Sample_Path": ids(df["Sample_Path"].tolist()), "Channel": ids(df["Channel"].tolist()),
+            "Speaker_ID": ids(df["Speaker_ID"].tolist()), "Database": ids(df["Database"].tolist()),
+            "Transcription": ids(texts)}
+
+
+def gather_utterance_results(dist, df, dst, tsv_path, params, rank=0, world=1):
+    """The utterance stage's one exchange (the role of src/postprocess/merge_aligned_files.py:17-25 without a
+    shared results directory): every rank turns the result TSVs of ITS files -- written now or by an earlier,
+    resumed run -- into fixed-width float64 records
+        (file, row in the file, start and end of the id, channel, length, start, end, score, text, speaker, database)
+    (strings by their number in ``_utterance_vocabularies``), the records are all-gathered
+    (``sharding.gather_records``: RCCL over xGMI on GPUs), and rank 0 writes ``<name>_aligned.tsv`` -- the file
+    ``formats.merge_aligned_files`` makes of the per-file TSVs, byte for byte.  Returns its path on rank 0."""
+    import torch
+
+    from . import sharding
+    voc = _utterance_vocabularies(df, params)
+    paths = list(dict.fromkeys(df["Sample_Path"].tolist()))
+    mine = sharding.assign_units(_file_costs(df, paths), world)[rank]
+    recs = []
+    for f in mine:
+        out = result_path(dst, paths[f])
+        if not (os.path.isfile(out) and os.path.getsize(out) > 0):
+            continue   # not aligned (yet): merge_aligned_files skips such files too
+        table = read_tsv(out)
+        stem = paths[f].split("/")[-1].replace(".wav", "")
+        for k, r in enumerate(table.to_dict(orient="records")):
+            id_start, id_end = str(r["Sample_ID"])[len(stem) + 1:].split("_")
+            recs.append([float(f), float(k), float(id_start), float(id_end), float(voc["Channel"][str(r["Channel"])]),
+                         float(r["Audio_Length"]), float(r["Start"]), float(r["End"]), float(r["Segment_Score"]),
+                         float(voc["Transcription"][str(r["Transcription"])]), float(voc["Speaker_ID"][str(r["Speaker_ID"])]),
+                         float(voc["Database"][str(r["Database"])])])
+    if dist is None:
+        rows = sorted(recs, key=lambda r: (r[0], r[1]))
+    else:
+        local = torch.tensor(recs, dtype=torch.float64).reshape(-1, 12)
+        if dist.get_backend() == "nccl":
+            local = local.cuda()
+        rows = []
+        for part in sharding.gather_records(local, dist):
+            rows.extend(part.cpu().tolist())
+        rows.sort(key=lambda r: (r[0], r[1]))
+    if rank != 0 or not rows:
+        return None
+    back = {k: list(dict.fromkeys(df[k].tolist())) for k in ("Channel", "Speaker_ID", "Database")}
+    texts = list(voc["Transcription"])
+    table = []
+    for f, _, id_start, id_end, ch, length, start, end, score, text, spk, db in rows:
+        path = paths[int(f)]
+        stem = path.split("/")[-1].replace(".wav", "")
+        table.append(["_".join([stem, str(id_start), str(id_end)]), path, back["Channel"][int(ch)], length, start, end, score,
+                      texts[int(text)], back["Speaker_ID"][int(spk)], back["Database"][int(db)]])
+    out = os.path.join(dst, tsv_path.split("/")[-1].replace(".tsv", "") + "_aligned.tsv")
+    _write_tsv_atomic(out, table, UTT_COLUMNS)
+    return out
 
 
 # ------------------------------------------------------------------------- word-level stage
@@ -203,39 +273,51 @@ def _word_row(row, clip_start, start, end, score):
             row["Speaker_ID"], row["Wanted_Text"].lower(), row["Database"]]
 
 
+def _emissions(aligner, waveforms, batch_lpz, frames_fn=None):
+    """Log-posteriors of a chunk of clips: one encoder forward each, the reference's way
+    (word_level_alignment.py:89, search_on_speech.py:74), or one padded forward for the chunk."""
+    if batch_lpz and len(waveforms) > 1 and hasattr(aligner, "get_lpz_batch"):
+        return aligner.get_lpz_batch(waveforms, frames_fn)
+    return [aligner.get_lpz(w) for w in waveforms]
+
+
 def word_hits(asr_model, aligner, records, indices, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
-              right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
+              right_offset=0.0, log=None, rows_per_launch=2048, number_to_words=None, batch_lpz=False, frames_fn=None):
     """Row loop of word_level_alignment.main (:35-135) over ``records[i] for i in indices`` ->
-    fixed-width records ``(i, clip_start, start, end, score)``: what a rank hands to the gather."""
+    fixed-width records ``(i, clip_start, start, end, score)``: what a rank hands to the gather.
+
+    Rows go through in chunks of ``rows_per_launch``: load and normalise the clips, encode them, align the
+    chunk in ONE launch, keep the records, drop the audio -- a rank never holds more than a chunk of waveforms
+    (10 000 rows of a few seconds each are gigabytes)."""
     log = log or (lambda m: None)
-    prepared = []
-    for i in indices:
-        row = records[i]
-        audio_path = row["Sample_Path"]
-        if time_info:
-            clip_start, clip_end = float(row["Start"]), float(row["End"])
-            clip_length = clip_end - clip_start
-        else:
-            clip_start, clip_end = 0.0, float(row["Audio_Length"])
-            clip_length = clip_end
-        try:
-            src = opener(audio_path)
-            clip, sr = src.load(int(clip_start * src.sample_rate), int(clip_length * src.sample_rate))
-            waveform = asr_model.audio_normalizer(clip, sr)
-        except Exception:
-            print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
-            print("Ending execution as non-valid audio file has been provided.")
-            break   # the reference stops the whole run here (:63-66)
-        text = sentence_pieces(text_prep.normalize_transcript(row["Normalized_Transcription"], number_to_words).upper(),
-                               row["Wanted_Text"])
-        prepared.append((i, row, clip_start, clip_end, waveform, text))
-    out = []
-    for k in range(0, len(prepared), rows_per_launch):
-        chunk = prepared[k:k + rows_per_launch]
-        tasks = []
-        for _, row, _, _, waveform, text in chunk:
-            lpz = aligner.get_lpz(waveform)
-            tasks.append(aligner.prepare_segmentation_task(text, lpz, row["Sample_ID"], waveform.shape[0]))
+    indices = list(indices)
+    out, stopped = [], False
+    for k in range(0, len(indices), rows_per_launch):
+        chunk = []
+        for i in indices[k:k + rows_per_launch]:
+            row = records[i]
+            audio_path = row["Sample_Path"]
+            if time_info:
+                clip_start, clip_end = float(row["Start"]), float(row["End"])
+                clip_length = clip_end - clip_start
+            else:
+                clip_start, clip_end = 0.0, float(row["Audio_Length"])
+                clip_length = clip_end
+            try:
+                src = opener(audio_path)
+                clip, sr = src.load(int(clip_start * src.sample_rate), int(clip_length * src.sample_rate))
+                waveform = asr_model.audio_normalizer(clip, sr)
+            except Exception:
+                print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
+                print("Ending execution as non-valid audio file has been provided.")
+                stopped = True
+                break   # the reference stops the whole run here (:63-66); the rows before it are aligned
+            text = sentence_pieces(text_prep.normalize_transcript(row["Normalized_Transcription"], number_to_words).upper(),
+                                   row["Wanted_Text"])
+            chunk.append((i, row, clip_start, clip_end, waveform, text))
+        lpzs = _emissions(aligner, [c[4] for c in chunk], batch_lpz, frames_fn)
+        tasks = [aligner.prepare_segmentation_task(text, lpz, row["Sample_ID"], waveform.shape[0])
+                 for (_, row, _, _, waveform, text), lpz in zip(chunk, lpzs)]
         for (i, row, clip_start, clip_end, _, _), lines in zip(chunk, _aligned_lines(aligner, tasks)):
             wanted = row["Wanted_Text"]
             if isinstance(lines, AssertionError):
@@ -252,15 +334,18 @@ def word_hits(asr_model, aligner, records, indices, opener=WavFile, time_info=Tr
                     score = float(seg[4])
                     log("{0} | {1} | {2} | {3}".format(round(clip_start + start, 3), round(clip_start + end, 3), round(score, 3), seg[-1]))
                     out.append((float(i), clip_start, start, end, score))
+        del chunk, lpzs, tasks   # the clips and emissions of this chunk are not needed again
+        if stopped:
+            break
     return out
 
 
 def align_words(asr_model, aligner, df, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
-                right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
+                right_offset=0.0, log=None, rows_per_launch=2048, number_to_words=None, batch_lpz=False):
     """Row loop of word_level_alignment.main (:35-135) -> result rows (WORD_COLUMNS)."""
     records = df.to_dict(orient="records")
     hits = word_hits(asr_model, aligner, records, range(len(records)), opener, time_info, offset_time, left_offset,
-                     right_offset, log, rows_per_launch, number_to_words)
+                     right_offset, log, rows_per_launch, number_to_words, batch_lpz)
     return [_word_row(records[int(i)], cs, st, en, sc) for i, cs, st, en, sc in hits]
 
 
@@ -283,29 +368,28 @@ def normalized_query(wanted_text, number_to_words=None):
 
 
 def search_hits(asr_model, aligner, records, indices, wanted_text, opener=WavFile, offset_time=0.0, left_offset=0.0,
-                right_offset=0.0, log=None, rows_per_launch=256):
+                right_offset=0.0, log=None, rows_per_launch=2048, batch_lpz=False, frames_fn=None):
     """Row loop of search_on_speech.main (:45-120) over ``records[i] for i in indices`` (``wanted_text``
-    already normalised) -> records ``(i, clip_start, start, end, score)``."""
+    already normalised) -> records ``(i, clip_start, start, end, score)``; chunked like ``word_hits``."""
     log = log or (lambda m: None)
     query = "·" + wanted_text.strip() + "·"
-    prepared, waveform = [], None
-    for i in indices:
-        row = records[i]
-        clip_start, clip_end = float(row["Start"]), float(row["End"])
-        try:
-            src = opener(row["Sample_Path"])
-            clip, sr = src.load(int(clip_start * src.sample_rate), int((clip_end - clip_start) * src.sample_rate))
-            waveform = asr_model.audio_normalizer(clip, sr)
-        except Exception:   # the reference prints and goes on with the previous row's audio (:66-67)
-            print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
-        prepared.append((i, row, clip_start, clip_end, waveform))
-    out = []
-    for k in range(0, len(prepared), rows_per_launch):
-        chunk = prepared[k:k + rows_per_launch]
-        tasks = []
-        for _, row, _, _, wf in chunk:
-            lpz = aligner.get_lpz(wf)
-            tasks.append(aligner.prepare_segmentation_task(query, lpz, row["Sample_ID"], wf.shape[0]))
+    indices = list(indices)
+    out, waveform = [], None
+    for k in range(0, len(indices), rows_per_launch):
+        chunk = []
+        for i in indices[k:k + rows_per_launch]:
+            row = records[i]
+            clip_start, clip_end = float(row["Start"]), float(row["End"])
+            try:
+                src = opener(row["Sample_Path"])
+                clip, sr = src.load(int(clip_start * src.sample_rate), int((clip_end - clip_start) * src.sample_rate))
+                waveform = asr_model.audio_normalizer(clip, sr)
+            except Exception:   # the reference prints and goes on with the previous row's audio (:66-67)
+                print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
+            chunk.append((i, row, clip_start, clip_end, waveform))
+        lpzs = _emissions(aligner, [c[4] for c in chunk], batch_lpz, frames_fn)
+        tasks = [aligner.prepare_segmentation_task(query, lpz, row["Sample_ID"], wf.shape[0])
+                 for (_, row, _, _, wf), lpz in zip(chunk, lpzs)]
         for (i, row, clip_start, clip_end, _), lines in zip(chunk, _aligned_lines(aligner, tasks)):
             if isinstance(lines, AssertionError):
                 log(str(lines))
@@ -322,16 +406,17 @@ def search_hits(asr_model, aligner, records, indices, wanted_text, opener=WavFil
                     log("{0} | {1} | {2} | {3}".format(round(clip_start + start, 3), round(clip_start + end, 3), round(score, 3),
                                                        seg[-1].replace("·", "")))
                     out.append((float(i), clip_start, start, end, score))
+        del chunk, lpzs, tasks
     return out
 
 
 def search_on_speech(asr_model, aligner, df, wanted_text, opener=WavFile, offset_time=0.0, left_offset=0.0,
-                     right_offset=0.0, log=None, rows_per_launch=256, number_to_words=None):
+                     right_offset=0.0, log=None, rows_per_launch=2048, number_to_words=None, batch_lpz=False):
     """Row loop of search_on_speech.main (:45-120) -> result rows (SOS_COLUMNS)."""
     wanted_text = normalized_query(wanted_text, number_to_words)
     records = df.to_dict(orient="records")
     hits = search_hits(asr_model, aligner, records, range(len(records)), wanted_text, opener, offset_time, left_offset,
-                       right_offset, log, rows_per_launch)
+                       right_offset, log, rows_per_launch, batch_lpz)
     return [_sos_row(records[int(i)], wanted_text, cs, st, en, sc) for i, cs, st, en, sc in hits]
 
 
@@ -366,8 +451,10 @@ def _load_model_and_aligner(args, **aligner_kwargs):
         run_opts = {"device": "cuda:%d" % dev}
         engine = _native.Engine(dev)   # the DP engine of THIS rank's GPU, not device 0
     asr_model = EncoderASR.from_hparams(source=args.asr_hub, savedir=args.asr_savedir, run_opts=run_opts)
+    # model on a GPU: the log-posteriors stay in HBM and feed the DP kernels where they are (no PCIe round
+    # trip per window; the reference computes them once per window, iterative_utterance_alignment.py:201)
     return asr_model, CTCSegmentation(asr_model, kaldi_style_text=False, time_stamps="fixed", engine=engine,
-                                      **aligner_kwargs)
+                                      keep_lpz_on_device=engine is not None, **aligner_kwargs)
 
 
 def _process_group():
@@ -435,6 +522,13 @@ def utterance_parser():
     p.add_argument("--max_text_to_audio_prop_exec", type=int, default=10)
     # not a flag of the reference: shrunk texts aligned ahead with every request (0 = one text per launch)
     p.add_argument("--speculate", type=int, default=1)
+    # not flags of the reference either: audio files advanced in lockstep (one launch per round carries a window of
+    # each), and whether a round's windows share one padded encoder forward (see CTCSegmentation.get_lpz_batch)
+    p.add_argument("--files_per_round", type=int, default=32)
+    p.add_argument("--batch_lpz", action="store_true")
+    # ... and the merge step of align_utterances.sh done in-process: the ranks gather their result records and rank 0
+    # writes <tsv name>_aligned.tsv into --dst (what src/postprocess/merge_aligned_files.py makes of the per-file TSVs)
+    p.add_argument("--gather", action="store_true")
     return p
 
 
@@ -451,9 +545,22 @@ def utterance_main(args, asr_model=None, aligner=None, opener=WavFile):
         max_window_size=args.max_window_size, window_to_stop=args.window_to_stop,
         min_text_to_audio_prop=args.min_text_to_audio_prop,
         max_text_to_audio_prop_exec=args.max_text_to_audio_prop_exec)
-    rank, world = _rank_world()
-    return align_utterance_files(asr_model, aligner, read_tsv(df_path), read_tsv(vad_path), args.dst,
-                                 args.logs_path, params, opener, rank, world, speculate=getattr(args, "speculate", 1))
+    gather = bool(getattr(args, "gather", False))
+    dist = None
+    if gather:
+        dist, rank, world = _process_group()
+    else:
+        rank, world = _rank_world()
+    df = read_tsv(df_path)
+    written = align_utterance_files(asr_model, aligner, df, read_tsv(vad_path), args.dst,
+                                    args.logs_path, params, opener, rank, world,
+                                    files_per_round=max(1, int(getattr(args, "files_per_round", 32))),
+                                    speculate=getattr(args, "speculate", 1), batch_lpz=bool(getattr(args, "batch_lpz", False)))
+    if gather:
+        merged = gather_utterance_results(dist, df, args.dst, df_path, params, rank, world)
+        if merged:
+            print("Aligned partition written to " + merged)
+    return written
 
 
 def word_parser(search=False):
@@ -471,6 +578,10 @@ def word_parser(search=False):
     p.add_argument("--logs_path", default="")
     if search:
         p.add_argument("--text", default="")
+    # not flags of the reference: rows per DP launch (a chunk's clips are loaded, encoded, aligned and dropped
+    # together) and one padded encoder forward per chunk instead of one per row
+    p.add_argument("--rows_per_launch", type=int, default=2048)
+    p.add_argument("--batch_lpz", action="store_true")
     return p
 
 
@@ -486,7 +597,8 @@ def word_main(args, asr_model=None, aligner=None, opener=WavFile, number_to_word
     records = read_tsv(args.tsv_path).to_dict(orient="records")
     mine = sharding.assign_units(_row_costs(records), world)[rank]
     hits = word_hits(asr_model, aligner, records, mine, opener, args.time_info, args.offset_time, args.left_offset,
-                     args.right_offset, log, number_to_words=number_to_words)
+                     args.right_offset, log, rows_per_launch=max(1, int(getattr(args, "rows_per_launch", 2048))),
+                     number_to_words=number_to_words, batch_lpz=bool(getattr(args, "batch_lpz", False)))
     hits = _gather_hits(dist, hits, world)
     if rank != 0:
         return None
@@ -507,7 +619,8 @@ def search_main(args, asr_model=None, aligner=None, opener=WavFile, number_to_wo
     records = read_tsv(args.tsv_path).to_dict(orient="records")
     mine = sharding.assign_units(_row_costs(records), world)[rank]
     hits = search_hits(asr_model, aligner, records, mine, wanted, opener, args.offset_time, args.left_offset,
-                       args.right_offset, log)
+                       args.right_offset, log, rows_per_launch=max(1, int(getattr(args, "rows_per_launch", 2048))),
+                       batch_lpz=bool(getattr(args, "batch_lpz", False)))
     hits = _gather_hits(dist, hits, world)
     if rank != 0:
         return None
