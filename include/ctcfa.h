@@ -51,9 +51,10 @@ extern "C" {
                                               caught at iterative_utterance_alignment.py:390 */
 #define CTCFA_ST_BACKTRACK_FAILED 2        /* IndexError re-raised by ctc_segmentation()      */
 #define CTCFA_ST_WINDOWED_UNSUPPORTED 3    /* windowed regime with T*4 bytes > LDS (T > ~40 000 frames) */
-#define CTCFA_ST_TEXT_TOO_LONG 4           /* more label columns than one fill workgroup covers (> ~7 400
-                                              with T <= min_window_size); the other segments of the batch
-                                              are aligned */
+#define CTCFA_ST_TEXT_TOO_LONG 4           /* more label columns than one fill workgroup covers
+                                              (ctcfa_max_label_columns: 5 485 for a 32-entry vocabulary,
+                                              5 119 for the others up to 128, 961 above) with
+                                              T <= min_window_size; the other segments of the batch are aligned */
 #define CTCFA_ST_INTERNAL 5                /* a wave of the fill kernel gave up waiting for a progress
                                               counter (bounded spins: a bug must not hang the GPU) */
 
@@ -92,12 +93,25 @@ typedef struct ctcfa_plan_info {
 int ctcfa_version(void);
 const char* ctcfa_status_string(int status);
 
+/* How the library was compiled.  0 = the product build.  Anything else is a kernel-tuning build
+ * (tools/build_variant.sh) and must never serve results: ablated builds leave out parts of the
+ * fill kernel's hand-over (WRONG results, timing only), stamp builds write cycle counts into output
+ * buffers.  The Python binding refuses to load such a library unless CTCFA_ALLOW_TUNING_BUILD=1. */
+#define CTCFA_BUILD_ABLATED   1   /* -DCTCFA_ABL > 0 */
+#define CTCFA_BUILD_STAMPS    2   /* -DCTCFA_STAMP / -DCTCFA_BT_STAMP */
+#define CTCFA_BUILD_ONE_PITCH 4   /* -DCTCFA_DEV_VP32_ONLY: vocabularies up to 32 entries only */
+#define CTCFA_BUILD_RETUNED   8   /* any other tuning macro off its default */
+int ctcfa_build_flags(void);
+
 /* Engine.  device >= 0 selects the HIP device.  One call at a time per engine: it owns a HIP
  * stream and a grow-only device scratch that ctcfa_align_batch reuses from call to call (the
  * reference runs one alignment process per worker: align_utterances.sh:127-137). */
 int ctcfa_engine_create(ctcfa_engine** out, int device);
 void ctcfa_engine_destroy(ctcfa_engine* eng);
 const char* ctcfa_last_error(const ctcfa_engine* eng);
+/* Label columns (ground_truth_mat rows) the widest launch shape of the fill kernel covers for this
+ * vocabulary: a longer text is status CTCFA_ST_TEXT_TOO_LONG for its segment. */
+int ctcfa_max_label_columns(const ctcfa_engine* engine, int32_t vocab);
 void ctcfa_default_params(ctcfa_params* p); /* CtcSegmentationParameters defaults, flags = 2 */
 
 /*
@@ -193,7 +207,10 @@ int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, in
  * member are served by that member's fill (column c of the trellis depends on columns <= c only): one
  * fill, one backtrack + scoring per member, results identical to separate calls.  Other members
  * (different text, equal length, status != 0, vocab > 128, T > min_window_size, more than 15 prefixes,
- * two prefixes ending in the same lane) are filled by themselves over the shared emissions.
+ * two prefixes ending in the same lane) are filled by themselves over the shared emissions -- and so
+ * is every member when the batch needs fill tiles wider than two columns per lane (texts of more than
+ * ~1 700 label columns: only the one- and two-column tiles carry the "watch column" variant of the row
+ * loop), silently: the results do not change, only the number of fills (ctcfa_plan_get_sharing).
  * Inputs other than `lpz` and all outputs are laid out exactly as for ctcfa_align_batch (every
  * segment has its own labels, utt_begin, frame_of_label, char_prob, ... regions).
  * lpz_on_device != 0: `lpz` is a device pointer and `stream` the hipStream_t it was produced on

@@ -27,6 +27,7 @@ EXPORTS = (
     "ctcfa_plan_get_timings",
     "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch", "ctcfa_align_batch_resident",
     "ctcfa_align_batch_shared", "ctcfa_plan_create_shared", "ctcfa_plan_get_sharing", "ctcfa_align_batch_spans",
+    "ctcfa_build_flags", "ctcfa_max_label_columns",
 )
 
 
@@ -76,6 +77,13 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU fallback. "
             "Run __graft_entry__.build().")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.ctcfa_build_flags.restype = ctypes.c_int
+    flags = lib.ctcfa_build_flags()
+    if flags and os.environ.get("CTCFA_ALLOW_TUNING_BUILD") != "1":
+        raise NativeLibraryError(
+            f"{LIB_PATH} is a kernel-tuning build (ctcfa_build_flags() = {flags}: 1 ablated -- WRONG results, 2 cycle "
+            "stamps in output buffers, 4 one vocabulary pitch, 8 retuned): not a library to align with.  "
+            "Set CTCFA_ALLOW_TUNING_BUILD=1 for the tuning tools.")
     vp = ctypes.c_void_p
     i32p = ctypes.POINTER(ctypes.c_int32)
     lib.ctcfa_version.restype = ctypes.c_int
@@ -83,6 +91,8 @@ def load():
     lib.ctcfa_status_string.argtypes = [ctypes.c_int]
     lib.ctcfa_last_error.restype = ctypes.c_char_p
     lib.ctcfa_last_error.argtypes = [vp]
+    lib.ctcfa_max_label_columns.argtypes = [vp, ctypes.c_int32]
+    lib.ctcfa_max_label_columns.restype = ctypes.c_int
     lib.ctcfa_engine_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.ctcfa_engine_destroy.argtypes = [vp]
     lib.ctcfa_engine_destroy.restype = None
@@ -154,6 +164,10 @@ class Engine:
         if getattr(self, "_h", None):
             self._lib.ctcfa_engine_destroy(self._h)
             self._h = None
+
+    def max_label_columns(self, vocab):
+        """Label columns the widest fill launch shape covers for this vocabulary (more: status 4)."""
+        return int(self._lib.ctcfa_max_label_columns(self._h, int(vocab)))
 
     def __del__(self):
         try:

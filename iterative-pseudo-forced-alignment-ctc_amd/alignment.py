@@ -253,7 +253,7 @@ class CTCSegmentation:
 
     @staticmethod
     def _result_dict(task, res):
-        cs._raise_for_status(res["status"])
+        cs._raise_for_status(res["status"], res.get("error"))
         config = task.config
         timings = res["frame_of_label"].astype(np.int64) * config.index_duration_in_seconds
         segments = list(zip(res["seg_start"].tolist(), res["seg_end"].tolist(), res["seg_score"].tolist()))
@@ -289,7 +289,7 @@ class CTCSegmentation:
         for task, r in zip(tasks, res):
             try:
                 out.append(self._result_dict(task, r))
-            except (AssertionError, IndexError, NotImplementedError) as e:
+            except (AssertionError, IndexError, NotImplementedError, ValueError) as e:
                 if raise_errors:
                     raise
                 out.append(e)

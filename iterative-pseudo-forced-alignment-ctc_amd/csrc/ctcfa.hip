@@ -45,6 +45,7 @@ struct ctcfa_engine {
     size_t h_out_cap = 0;
     int64_t trace_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // CTCFA_CALL_TRACE
     int64_t trace_calls = 0;
+    int32_t run_seq = 0;   // runs are numbered (1, 2, ...): what a fill writes into its workspace's error word when a wait gives up
 };
 
 // Workspaces (trace words + last-column scores) a plan rotates through in the pipelined entry.  Two would do for
@@ -84,7 +85,8 @@ struct ctcfa_plan {
     int ev_stride = 1;       // record timing events on every ev_stride-th run
     int64_t run_counter = 0;
     void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*) = nullptr;
+                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int) = nullptr;
+    int32_t last_run[kWorkspaces] = {0, 0, 0, 0};   // number of the run that last filled workspace q (its backtrack looks for it in the error word)
     // shared fills: watch columns of every group, the widest group, unique emission frames
     std::vector<ctcfa::WatchDesc> watch;
     ctcfa::WatchDesc* d_watch = nullptr;
@@ -119,8 +121,10 @@ int set_err(ctcfa_engine* e, int code, const std::string& msg) {
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
+    bool ok = true;   // false: the engine's device could not be made current (the entry point reports CTCFA_ERR_HIP)
     explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+        if (hipGetDevice(&prev) != hipSuccess) ok = false;
+        else if (prev != device) ok = switched = (hipSetDevice(device) == hipSuccess);
     }
     ~DeviceGuard() {
         if (switched) (void)hipSetDevice(prev);
@@ -128,6 +132,10 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
+
+#define GUARD_DEVICE(eng)                                                                         \
+    DeviceGuard on_device((eng)->device);                                                        \
+    if (!on_device.ok) return set_err(eng, CTCFA_ERR_HIP, "hipSetDevice: the engine's device could not be made current")
 
 #define HIP_TRY(eng, expr)                                                                   \
     do {                                                                                     \
@@ -137,7 +145,7 @@ struct DeviceGuard {
     } while (0)
 
 using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                        const ctcfa::FillRoles*, const ctcfa::WatchDesc*);
+                        const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int);
 
 template <int VP, bool CK>
 FillFn fill_for_k(int K) {
@@ -167,7 +175,7 @@ FillFn fill_any(int K, bool ck) {
 FillFn select_fill(int K, int VP, bool ck) {
     switch (VP) {
         case 32: return fill_any<32>(K, ck);
-#ifndef CTCFA_DEV_VP32_ONLY  // tuning builds (tools/make_variant.py): one pitch compiles in a fifth of the time
+#ifndef CTCFA_DEV_VP32_ONLY  // tuning builds (tools/build_variant.sh): one pitch compiles in a fifth of the time
         case 40: return fill_any<40>(K, ck);
         case 48: return fill_any<48>(K, ck);
         case 56: return fill_any<56>(K, ck);
@@ -257,6 +265,12 @@ int waves_of(int W, int nprod) {
     return W + nprod;
 }
 
+// launch bounds of fill_kernel<K, ..>: 16 waves; K >= 10: 320 threads, K == 8: 512
+bool shape_launchable(int K, int W, int nprod) {
+    const int waves_per_wg = waves_of(W, nprod);
+    return !(W > 16 - nprod || (K >= 10 && waves_per_wg > 5) || (K == 8 && waves_per_wg > 8));
+}
+
 int lds_bytes_fill(int NS, int W, int K, int VP, int nwatch = 0) {
     // emission ring (NS slots) + exchange rings + last-column ring + counters + sink
     // (+ shared fills: a ring and a target offset per watch column)
@@ -265,6 +279,27 @@ int lds_bytes_fill(int NS, int W, int K, int VP, int nwatch = 0) {
 }
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+int vocab_pitch(int vocab) {
+    return vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
+           : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
+}
+
+// Label columns the widest launch shape of the fill kernel covers (more: status CTCFA_ST_TEXT_TOO_LONG for that
+// segment).  The same rules as pick_shape: tile widths and wave counts of the launch bounds, a ring of 4 slots
+// or, where only that fits the LDS, 3.
+int label_column_limit(int lds_limit, int VP, int nprod, bool gather) {
+    if (gather) return 15 * 64 + 1;
+    int c_limit = 0;
+    for (int K : kKs) {
+        for (int W = 16 - nprod; W >= 1; --W) {
+            if (!shape_launchable(K, W, nprod) || lds_bytes_fill(3, W, K, VP) > lds_limit) continue;
+            c_limit = std::max(c_limit, W * tile_useful_cols(K) - (K - 1));
+            break;
+        }
+    }
+    return c_limit;
+}
 
 // Launch-shape choice from a two-bound cost model of the fill kernel (constants fitted
 // to tools/shape_search2.py sweeps, cycles per trellis row):
@@ -306,7 +341,7 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
         const int U = tile_useful_cols(K);
         const int W = (Cmax + (K - 1) + U - 1) / U;   // (the left padding can take up to K-1 columns)
         const int waves_per_wg = waves_of(W, nprod);
-        if (W > 16 - nprod || (K >= 10 && waves_per_wg > 5) || (K == 8 && waves_per_wg > 8)) continue;  // launch bounds: K >= 10: 320 threads, K == 8: 512
+        if (!shape_launchable(K, W, nprod)) continue;
         // Ring slots: 4 (the producer up to three blocks ahead of the tiles); 3 when that is what lets the
         // workgroups a CU needs, and two backtrack workgroups of the previous batch, share its LDS.
         int NS = ns_forced ? ns_forced : 4;
@@ -355,6 +390,24 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
 extern "C" {
 
 int ctcfa_version(void) { return CTCFA_VERSION; }
+
+int ctcfa_build_flags(void) {
+    int f = 0;
+#if CTCFA_ABL > 0
+    f |= CTCFA_BUILD_ABLATED;
+#endif
+#if defined(CTCFA_STAMP) || defined(CTCFA_BT_STAMP)
+    f |= CTCFA_BUILD_STAMPS;
+#endif
+#ifdef CTCFA_DEV_VP32_ONLY
+    f |= CTCFA_BUILD_ONE_PITCH;
+#endif
+#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_PEEK_LEAD != 3 || \
+    CTCFA_NBR_SLEEP != 1 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 0 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
+    f |= CTCFA_BUILD_RETUNED;
+#endif
+    return f;
+}
 
 const char* ctcfa_status_string(int s) {
     switch (s) {
@@ -408,6 +461,7 @@ int ctcfa_engine_create(ctcfa_engine** out, int device) {
 
 void ctcfa_engine_destroy(ctcfa_engine* eng) {
     if (!eng) return;
+    DeviceGuard on_device(eng->device);
     if (eng->trace_calls) {
         const char* names[7] = {"plan", "pack", "enqueue uploads", "launch kernels", "enqueue download", "wait", "unpack"};
         std::fprintf(stderr, "ctcfa call trace, %lld calls, us per call:", (long long)eng->trace_calls);
@@ -424,8 +478,17 @@ void ctcfa_engine_destroy(ctcfa_engine* eng) {
 
 const char* ctcfa_last_error(const ctcfa_engine* eng) { return eng ? eng->err.c_str() : g_err.c_str(); }
 
+int ctcfa_max_label_columns(const ctcfa_engine* eng, int32_t vocab) {
+    if (!eng || vocab <= 0) return 0;
+    const bool gather = vocab > 128;
+    const int VP = gather ? 128 : vocab_pitch(vocab);
+    const int nprod = (!gather && (VP > 32 || vocab < 32)) ? 2 : 1;
+    return label_column_limit(eng->lds_limit, VP, nprod, gather);
+}
+
 void ctcfa_plan_destroy(ctcfa_plan* plan) {
     if (!plan) return;
+    DeviceGuard on_device(plan->eng ? plan->eng->device : 0);
     if (plan->scratch_owned) {
         plan->d_segs = nullptr;
         plan->d_roles = nullptr;
@@ -463,6 +526,8 @@ hipError_t scratch_get(ctcfa_engine* eng, int slot, void** p, size_t bytes) {
         sl.cap = 0;
         const size_t cap = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&sl.p, cap);
+        if (e != hipSuccess) return e;
+        e = hipMemset(sl.p, 0, cap);   // (the workspace's error word must not start out as some future run's number)
         if (e != hipSuccess) return e;
         sl.cap = cap;
     }
@@ -504,7 +569,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                        "vocab > 128 needs preamble_transition_cost_zero (the package default)");
     if (gratis && gather)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero is not built for the wide-vocabulary fill kernel");
-    DeviceGuard on_device(eng->device);
+    GUARD_DEVICE(eng);
 
     ctcfa_plan* pl = new ctcfa_plan();
     pl->eng = eng;
@@ -515,8 +580,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // LDS row pitch: the vocabulary rounded up to a compiled size.  Character vocabularies of
     // wav2vec2 models sit between 32 and 64 (the reference's Spanish model: 38 tokens), where
     // a pitch of 64 would cost a second workgroup per CU.
-    pl->VP = vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
-           : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
+    pl->VP = vocab_pitch(vocab);
     pl->have_utt = (U != nullptr);
 
     for (int b = 0; b < batch; ++b) {
@@ -542,17 +606,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.
     const int64_t lds_dyn_max = (int64_t)eng->lds_limit - 64;  // the windowed kernel also has a few static words
-    int c_limit = 0;   // label columns the widest fill shape can take
-    if (gather) c_limit = 15 * 64 + 1;
-    else
-        for (int K : kKs) {
-            const int wmax = K >= 10 ? 4 : K == 8 ? 8 - nprod : 16 - nprod;
-            for (int W = wmax; W >= 1; --W)
-                if (lds_bytes_fill(4, W, K, pl->VP) <= eng->lds_limit) {
-                    c_limit = std::max(c_limit, W * tile_useful_cols(K) - (K - 1));
-                    break;
-                }
-        }
+    const int c_limit = label_column_limit(eng->lds_limit, pl->VP, nprod, gather);   // label columns the widest fill shape can take
     std::vector<int32_t> pre(batch, CTCFA_ST_OK);
     int Cmax = 2, Tmax = 1;
     for (int b = 0; b < batch; ++b) {
@@ -613,8 +667,12 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         // (the host-buffer entry runs fill and backtrack one after the other: there the longer
         // backtrack only pays once the fill is several times its length)
         const int64_t nf = n_fill_of();
+        // Round 3 (profiles/r03_modes.txt): with the strider backtrack, checkpoint mode is ahead for every batch of
+        // long segments -- 512 x 3000 frames: 128 label columns 0.106 against 0.139 ms per step, 254: 0.120 / 0.164,
+        // 380: 0.142 / 0.207, 640: 0.156 / 0.253 -- and level or a little behind for short windows (4096 x 425 x 54:
+        // 0.128 / 0.121; the word-level and corpus streams: +-2 %), which stay with decision words.
         const bool pays = use_scratch ? nf * Cmax >= 1024 * 1024
-                                      : Cmax >= 544 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
+                                      : Cmax >= 544 || Tmax >= 900 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
         if (gratis) pl->ckpt = true;   // (vocab <= 64 checked above)
     }
@@ -826,14 +884,15 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         PLAN_TRY(scratch_get(eng, kSlotBits, reinterpret_cast<void**>(&pl->d_bits[0]),
                              sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
         PLAN_TRY(scratch_get(eng, kSlotLastcol, reinterpret_cast<void**>(&pl->d_lastcol[0]),
-                             sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+                             sizeof(float) * (size_t)(std::max<int64_t>(1, pl->total_T) + 4)));   // (+ the error word)
     } else {
         PLAN_TRY(hipMalloc(&pl->d_roles, sizeof(ctcfa::FillRoles)));
         PLAN_TRY(hipMemcpy(pl->d_roles, &pl->roles, sizeof(ctcfa::FillRoles), hipMemcpyHostToDevice));
         PLAN_TRY(hipMalloc(&pl->d_segs, sizeof(SegDesc) * (size_t)batch));
         PLAN_TRY(hipMemcpy(pl->d_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch, hipMemcpyHostToDevice));
         PLAN_TRY(hipMalloc(&pl->d_bits[0], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
-        PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+        PLAN_TRY(hipMalloc(&pl->d_lastcol[0], sizeof(float) * (size_t)(std::max<int64_t>(1, pl->total_T) + 4)));
+        PLAN_TRY(hipMemset(pl->d_lastcol[0] + std::max<int64_t>(1, pl->total_T), 0, 16));   // the error word
         if (!pl->watch.empty()) {
             PLAN_TRY(hipMalloc(&pl->d_watch, sizeof(ctcfa::WatchDesc) * pl->watch.size()));
             PLAN_TRY(hipMemcpy(pl->d_watch, pl->watch.data(), sizeof(ctcfa::WatchDesc) * pl->watch.size(), hipMemcpyHostToDevice));
@@ -843,7 +902,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
     if (pl->lds_bt > 48 * 1024)
-        PLAN_TRY(hipFuncSetAttribute(!pl->ckpt ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel<0>)
+        PLAN_TRY(hipFuncSetAttribute(!pl->ckpt ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel)
                                                 : reinterpret_cast<const void*>(select_strider(pl->VP)),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
     if (!pl->win_list.empty()) {
@@ -895,6 +954,7 @@ int ctcfa_plan_set_timing_stride(ctcfa_plan* pl, int stride) {
 int ctcfa_plan_set_timing(ctcfa_plan* pl, int slots) {
     if (!pl || slots < 0 || slots > 4096) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
+    GUARD_DEVICE(eng);   // (events belong to the device that is current when they are created)
     if (slots > 0 && slots < 2 * kWorkspaces) slots = 2 * kWorkspaces;  // the pipelined entry looks at the event of run k - kWorkspaces
     if (pl->side) {
         // a pending hand-over may be one of the timing events about to be destroyed
@@ -948,11 +1008,15 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
 #else
     float* lastcol_arg = pl->d_lastcol[ws];
 #endif
+    ctcfa_engine* eng = pl->eng;
+    eng->run_seq = eng->run_seq == 0x7fffffff ? 1 : eng->run_seq + 1;
+    pl->last_run[ws] = eng->run_seq;
     hipExtLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, start, stop, 0,
                           pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], lastcol_arg, pl->V, pl->prm.blank,
                           ((pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0) |
                               ((pl->prm.flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) ? 2 : 0),
-                          (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch);
+                          (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch,
+                          reinterpret_cast<int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)), (int)pl->last_run[ws]);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }
@@ -985,10 +1049,12 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     if (const char* e = std::getenv("CTCFA_SB_WINDOWS")) bp.windows = std::max(1, std::min(3, std::atoi(e)));
     bp.dur = pl->prm.index_duration;
     const ctcfa::BtArgs ba{pl->d_segs, a.d_lpz, a.d_labels, want_seg ? a.d_utt_begin : nullptr, pl->d_bits[ws],
-                           pl->d_lastcol[ws], pl->gather ? nullptr : &pl->d_roles->spin_timeout, bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
+                           pl->d_lastcol[ws],
+                           pl->gather ? nullptr : reinterpret_cast<const int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
+                           pl->last_run[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
                            want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
     if (!pl->ckpt)
-        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel<0>, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
+        hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
                               start, windowed ? nullptr : stop, 0, ba);
     else
         hipExtLaunchKernelGGL(select_strider(pl->VP), dim3(pl->B), dim3(64 * (pl->bt_waves + pl->bt_scorers)), pl->lds_bt, st,
@@ -1029,7 +1095,7 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
     bool want_seg = false;
     int rc = check_args(pl, a, &want_seg);
     if (rc != CTCFA_OK) return rc;
-    DeviceGuard on_device(eng->device);
+    GUARD_DEVICE(eng);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     // a pipelined run may still be reading workspace 0 on the side stream
     if (pl->bt_pending[0]) {
@@ -1056,11 +1122,12 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     int rc = check_args(pl, a, &want_seg);
     if (rc != CTCFA_OK) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
-    DeviceGuard on_device(eng->device);
+    GUARD_DEVICE(eng);
     if (!pl->side) {  // first use: the other workspaces, side stream, hand-over events
         for (int w = 1; w < kWorkspaces; ++w) {
             HIP_TRY(eng, hipMalloc(&pl->d_bits[w], sizeof(uint32_t) * (size_t)std::max<int64_t>(1, pl->bits_words)));
-            HIP_TRY(eng, hipMalloc(&pl->d_lastcol[w], sizeof(float) * (size_t)std::max<int64_t>(1, pl->total_T)));
+            HIP_TRY(eng, hipMalloc(&pl->d_lastcol[w], sizeof(float) * (size_t)(std::max<int64_t>(1, pl->total_T) + 4)));
+            HIP_TRY(eng, hipMemset(pl->d_lastcol[w] + std::max<int64_t>(1, pl->total_T), 0, 16));   // the error word
         }
         for (int w = 0; w < kWorkspaces; ++w) {
             HIP_TRY(eng, hipEventCreate(&pl->ev_fill_done[w]));  // (kernel-attached events carry timestamps)
@@ -1095,6 +1162,7 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
 int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
     if (!pl) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
+    GUARD_DEVICE(eng);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     for (int q = 0; q < kWorkspaces; ++q)
         if (pl->bt_pending[q]) {
@@ -1107,6 +1175,7 @@ int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
 int ctcfa_plan_get_timings(ctcfa_plan* pl, int n, float* fill_ms, float* backtrack_ms) {
     if (!pl || n <= 0 || !pl->ev_slots || n > pl->ev_slots || n > pl->ev_runs) return CTCFA_ERR_INVALID;
     ctcfa_engine* eng = pl->eng;
+    GUARD_DEVICE(eng);
     for (int i = 0; i < n; ++i) {
         const int64_t run = pl->ev_runs - n + i;
         hipEvent_t* ev = &pl->ev[(size_t)(run % pl->ev_slots) * 4];
@@ -1143,7 +1212,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
                const int32_t* labels, const int32_t* utt_begin, int32_t* frame_of_label, float* char_prob,
                int32_t* state, double* seg_start, double* seg_end, double* seg_score, int32_t* t_end,
                int32_t* status) {
-    DeviceGuard on_device(eng->device);
+    GUARD_DEVICE(eng);
     // CTCFA_CALL_TRACE=1 (tuning): where the host time of a call goes, printed when the engine is destroyed
     static const bool trace = std::getenv("CTCFA_CALL_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };

@@ -15,8 +15,9 @@
 // Kernels:
 //   fill_kernel<K,VP,CK>      T <= min_window_size, vocabulary <= 128: the hot one
 //   fill_gather_kernel        same, vocabulary > 128 (no LDS staging of vocabulary rows)
-//   backtrack_kernel<PB>      end cell, walk (over decision words, or recomputing them from the
-//                             checkpoint rows), per-frame outputs, scores
+//   backtrack_kernel          decision-word mode: end cell, walk over the decision words, per-frame outputs, scores
+//   stride_backtrack_kernel   checkpoint mode: the same outputs, the decisions recomputed from the checkpoint rows by
+//                             waves that work on 32-row blocks speculatively ("striders")
 //   windowed_kernel           T > min_window_size: the package's windowed regime, literally; also
 //                             every segment with a label matrix (multi-character tokens, S > 1)
 //
@@ -48,9 +49,6 @@
 #include <hip/hip_runtime.h>
 #ifndef CTCFA_PRODUCER_PRIO
 #define CTCFA_PRODUCER_PRIO 0
-#endif
-#ifndef CTCFA_TILE_PRIO
-#define CTCFA_TILE_PRIO 4
 #endif
 #ifndef CTCFA_VGPR_CAP
 #define CTCFA_VGPR_CAP 1
@@ -138,10 +136,6 @@ struct FillRoles {
     int32_t nprod;    // producer waves (1, or 2: each stages every other row)
     int32_t reserved[3];
     WaveRole wave[16];
-    // device copy only: set by a wave whose wait on a progress counter gave up (a lost counter would
-    // otherwise hang the GPU); the backtrack kernel turns it into status CTCFA_ST_INTERNAL for the batch
-    int32_t spin_timeout;
-    int32_t pad[3];
 };
 
 constexpr int kHaloRows = 16;       // rows between two refreshes of a tile's halo (a "group")
@@ -164,7 +158,9 @@ constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a los
 #ifdef CTCFA_DEBUG_SPIN
 #define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) printf("fill spin timeout: %s wg %d a %d b %d c %d T %d C %d\n", what, (int)blockIdx.x, (int)(a), (int)(b), (int)(c), T, C); } while (0)
 #else
-#define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) atomicOr(const_cast<int32_t*>(&roles->spin_timeout), 1); } while (0)
+// a wait on a progress counter gave up (a lost counter would otherwise hang the GPU): this run's number goes into the
+// workspace's error word; the backtrack of the same run turns it into status CTCFA_ST_INTERNAL for the batch
+#define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) atomicExch(fill_err, run_id); } while (0)
 #endif
 
 using lds_vint = volatile __attribute__((address_space(3))) int;   // counters in LDS
@@ -222,7 +218,8 @@ __launch_bounds__((K >= 10) ? 320 : (K >= 8) ? 512 : 1024)
 fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int cost_flags,
-            const FillRoles* __restrict__ roles, const WatchDesc* __restrict__ watch) {
+            const FillRoles* __restrict__ roles, const WatchDesc* __restrict__ watch,
+            int32_t* __restrict__ fill_err, int run_id) {
     // cost_flags: bit 0 = preamble_transition_cost_zero (column 0 stays for free), bit 1 =
     // blank_transition_cost_zero (a column labelled blank stays for free: the blank entry's m is 0)
     const bool preamble = (cost_flags & 1) != 0;
@@ -653,28 +650,10 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 
     // Tiles of one SIMD compete for issue slots by priority, then age: the later-dispatched waves
     // would always lose.  A tile is only ever waited for by its right neighbour, so the left ones go first.
-#if CTCFA_TILE_PRIO == 1
-    if (w < (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(1);
-#elif CTCFA_TILE_PRIO == 2
-    __builtin_amdgcn_s_setprio(1);
-#elif CTCFA_TILE_PRIO == 3
-    __builtin_amdgcn_s_setprio(2);
-#elif CTCFA_TILE_PRIO == 4   // later tiles first
+    // Shipped: the later half of the tiles first (measured on config 3, round 2: earlier tiles first 160 us, later
+    // half first 148, producer above the tiles 165-170, "a tile that had to wait steps back" 155).
     if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(1);
-#elif CTCFA_TILE_PRIO == 5 || CTCFA_TILE_PRIO == 6  // graduated: the further right, the higher
-    {
-        const int pr = W > 1 ? (w * 4) / W : 0;
-        if (pr >= 3) __builtin_amdgcn_s_setprio(3);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-    }
-#elif CTCFA_TILE_PRIO == 7  // later half 3, earlier half 1
-    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(1);
-#endif
 
     // Dead zone: column c cannot reach the end cell's column C-1 from rows t > T-C+c, so the
     // backtrack never visits those cells and they feed only other dead cells (in this tile or, through
@@ -835,23 +814,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             }
             if (i % kHaloRows == kHaloRows - 1 - kPollLead && CTCFA_ABL < 2) {
                 if (w > 0) {   // my neighbour's columns at the end of this group, for my next one
-#if CTCFA_TILE_PRIO == 6
-                    if (__builtin_amdgcn_readfirstlane(peek) < g + 1) __builtin_amdgcn_s_setprio(0);
-                    else {
-                        const int pr = W > 1 ? (w * 4) / W : 0;
-                        if (pr >= 3) __builtin_amdgcn_s_setprio(3);
-                        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-                        else __builtin_amdgcn_s_setprio(1);
-                    }
-#endif
-#if CTCFA_TILE_PRIO == 3
-                    // Issue slots of a SIMD go by priority, then age: a tile that keeps losing falls behind and
-                    // everybody upstream ends up waiting for it (ring space).  A tile that had to wait for its
-                    // neighbour is ahead and steps back; one that found the neighbour done is the one being
-                    // waited for and goes first.
-                    if (__builtin_amdgcn_readfirstlane(peek) < g + 1) __builtin_amdgcn_s_setprio(0);
-                    else __builtin_amdgcn_s_setprio(2);
-#endif
                     if (CTCFA_ABL < 1 && __builtin_expect(__builtin_amdgcn_readfirstlane(peek) < g + 1, 0)) {   // (normally it is 4+ rows ahead)
                         CTCFA_STAMP_BEGIN();
                         int f, spins = 0;
@@ -917,12 +879,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 
     for (int j = 0; j <= jlast; ++j, jslot = (jslot + 1 == NS) ? 0 : jslot + 1) {
         staged_seen = __builtin_amdgcn_readfirstlane(peek_sa < peek_sb ? peek_sa : peek_sb);
-#if CTCFA_TILE_PRIO == 3
-        if (w == 0) {   // (tile 0 has no neighbour to its left: it steps back when it runs into the producer)
-            if (staged_seen <= j) __builtin_amdgcn_s_setprio(0);
-            else __builtin_amdgcn_s_setprio(2);
-        }
-#endif
         if (__builtin_expect(staged_seen <= j, 0)) {   // emissions of block j (normally seen staged while block j-1 was computed)
             CTCFA_STAMP_BEGIN();
             for (int spins = 0;; ++spins) {
@@ -1148,19 +1104,8 @@ struct BtParams {
     double dur;       // index_duration
 };
 
-// Checkpoint mode (fill_kernel<.., CK = true>, V <= 64): the fill stores no decisions, only the
-// table row every 32-row block ends in.  The backtrack recomputes what it needs: the path drops at
-// most one column per row, so inside a block it stays within 32 columns of where it enters and
-// every cell it visits depends on 64 columns of the previous block's last row -- one wave, lane i
-// = column (pc - i), runs the fill's recurrence AND the residual comparison over those 32 rows
-// (same operations in the same order: bit-identical decisions), ~10 % of the cells the fill
-// touches.  Lanes whose left neighbours are outside the window go wrong one column per row; the
-// path is always ahead of that front (row r: garbage in lanes >= 63 - r, path in lanes <= 31 - r).
-// Waves 1-3 stage the emission rows of the coming blocks as (e, m) pairs in LDS meanwhile (row
-// pitch PB entries, the last one the start column's pseudo label, as in the fill).  One slot: wave
-// 0 takes a block's 32 pairs into registers at once, then the slot is free for the next block.
-// It shares its LDS with the char_probs copy of the later phases -- the kernel has to stay under
-// 15.8 KB of LDS to sit beside two fill workgroups on a CU.
+// (Checkpoint mode -- fill_kernel<.., CK = true>, V <= 64: the fill stores no decisions, only the table row every
+// 32-row block ends in -- has its own backtrack kernel, stride_backtrack_kernel below.)
 
 __device__ __forceinline__ float dpp_wave_shl1(float src) {
     // lane i <- src[lane i+1]; lane 63 <- 0 (bound_ctrl: the DPP folds into the consuming VALU op)
@@ -1312,7 +1257,8 @@ struct BtArgs {
     const int32_t* utt_begin;
     const uint32_t* bits;
     const float* lastcol;
-    const int32_t* fill_err;   // FillRoles::spin_timeout of the fill that produced bits / lastcol (NULL: none)
+    const int32_t* fill_err;   // error word of the workspace: == fill_run if a wait of the fill that produced bits / lastcol gave up (NULL: none)
+    int32_t fill_run;          // the number of this run
     BtParams p;
     int32_t* frame_of_label;
     float* char_prob;
@@ -1327,7 +1273,7 @@ struct BtArgs {
 // NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
 // `sync` separates the phases, `tick` is called between slices of work (the fused wave has to
 // take part in the fill workgroup's barriers while it lives).
-template <int NT, int PB, class Sync, class Tick>
+template <int NT, class Sync, class Tick>
 __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& sd, int tid, unsigned char* smem,
                                                float* red_v, int* red_t, int* sh_misc, Sync sync, Tick tick) {
     const BtParams& p = a.p;
@@ -1345,11 +1291,8 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     int32_t* __restrict__ t_end_out = a.t_end_out;
     int32_t* __restrict__ status_out = a.status_out;
     constexpr int kThreads = NT;
-    constexpr bool CK = PB > 0;
     int2* rec = reinterpret_cast<int2*>(smem);                   // per block: (entry column, switch mask)
-    uint8_t* labs = smem + p.rec_bytes;                                         // checkpoint mode: label copy (V <= 64: one byte each)
-    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes + p.lab_bytes);    // char_probs of this segment
-    float2* ering = reinterpret_cast<float2*>(cps);              // checkpoint mode, phase A: [32][PB] (e, m)
+    float* cps = reinterpret_cast<float*>(smem + p.rec_bytes);   // char_probs of this segment
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = kThreads / 64;
@@ -1383,7 +1326,7 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
         fail(sd.prestatus);
         return;
     }
-    if (a.fill_err && *a.fill_err) {   // the fill gave up on a progress counter: its trace is not to be trusted
+    if (a.fill_err && *a.fill_err == a.fill_run) {   // the fill gave up on a progress counter: its trace is not to be trusted
         fail(5);
         return;
     }
@@ -1419,317 +1362,8 @@ __device__ __forceinline__ void backtrack_body(const BtArgs& a, const SegDesc& s
     const int nblk = (T - 1 + kRows - 1) / kRows;
     for (int j = tid; j < nblk; j += kThreads) rec[j] = make_int2(-1, 0);
     for (int c = tid; c < C; c += kThreads) fol[c] = 0;
-    if constexpr (CK) {
-        for (int c = tid; c < C; c += kThreads) labs[c] = (uint8_t)seg_lab[c];  // [0] = -1 is never looked up
-    }
     sync();
 
-    if constexpr (CK) {
-        // ---- phase A, checkpoint mode: all four waves --------------------------------------
-        // (per-block barriers order LDS only: the producers' loads and the checkpoint prefetches
-        // stay in flight across them)
-        float bv = red_v[0];
-        int bt = red_t[0];
-#pragma unroll
-        for (int q = 1; q < NW; ++q) {
-            const float ov = red_v[q];
-            const int ot = red_t[q];
-            if (ot != 0x7fffffff && (bt == 0x7fffffff || ov > bv || (ov == bv && ot < bt))) {
-                bv = ov;
-                bt = ot;
-            }
-        }
-        int t_end = __builtin_amdgcn_readfirstlane(bt);
-        if (p.flags & 4u) t_end = T - 1;
-        int pc = C - 1 + shift;
-        if (t_end >= 1) {
-            const int jstart = (t_end - 1) >> 5;
-            // Roles: wave 0 recomputes decision words, wave 1 walks them, waves 2-3 stage emissions.
-            // Step j (j = jstart .. 0): the walker walks block j while wave 0 recomputes block j - 1,
-            // which it has to start before the walk knows where the path leaves block j: its lane 0
-            // is the column where the path ENTERED block j (pcj), and the path then enters block
-            // j - 1 at lane x = columns dropped in block j.  Row r of a recomputed block is wrong in
-            // lanes >= 63 - r (their left neighbours lie outside the wave) and the path sits in lanes
-            // <= x + 31 - r: fine for x <= 31.  x == 32 (a SWITCH in every row of block j) raises
-            // sh_misc[3] and block j - 1 is recomputed from its exact entry column at the start of
-            // the next step (slow path, as for the first block).
-            // Two LDS-only barriers per step: A (emission slot filled, decision words of block j and
-            // its entry column published) and B (slot and word buffer read, both may be overwritten);
-            // a third one, F, in the steps that take the slow path.
-            uint32_t* wbuf = reinterpret_cast<uint32_t*>(ering + kRows * PB);  // 64 words right after the emission slot
-            if (wave >= 2) {
-                // ======== producers: wave 2 stages rows 0-15 of every block, wave 3 rows 16-31.  Block
-                // jb is read in step jb + 1; its loads are issued in step jb + 4 and written to the
-                // slot in step jb + 2 (two register sets, by block parity).  Lane v < V stages
-                // vocabulary entry v of its rows, lane V (if there is one) the start column's pseudo
-                // entry; everything under ONE lane mask per block: put + issue have to fit in a step.
-                if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-                constexpr int kHalf = kRows / 2;
-                const int r0 = (wave - 2) * kHalf;
-                float e0[kHalf], e1[kHalf];
-                const bool preamble = (p.flags & 2u) != 0;
-                const bool is_pseudo = lane == V;             // no such lane when V == 64
-                const int woff = is_pseudo ? PB - 1 : lane;
-                auto issue = [&](int jb, float (&e)[kHalf]) {
-                    if (jb >= 0 && lane < V) {
-#pragma unroll
-                        for (int r = 0; r < kHalf; ++r) {
-                            int t = jb * kRows + 1 + r0 + r;
-                            t = t < T ? t : T - 1;   // rows past the end: decisions nobody reads
-                            e[r] = seg_lpz[(int64_t)t * V + lane];
-                        }
-                    }
-                };
-                auto put = [&](int jb, const float (&e)[kHalf]) {
-                    if (jb < 0) return;
-                    float2* slot = ering + r0 * PB + woff;
-                    if (preamble) {
-                        // (the start column's entry is (-inf, 0) in every row: written once, below -- three
-                        // instructions per row here instead of six; the producers are on the step's critical path)
-                        if (lane < V) {
-#pragma unroll
-                            for (int r = 0; r < kHalf; ++r) {
-                                const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
-                                slot[r * PB] = make_float2(e[r], max3f(lb, e[r], kProbMax));
-                            }
-                        }
-                    } else if (lane <= V) {
-#pragma unroll
-                        for (int r = 0; r < kHalf; ++r) {
-                            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
-                            const float m = max3f(lb, e[r], kProbMax);
-                            const float pm = __builtin_fmaxf(lb, kProbMax);  // start column's stay step
-                            slot[r * PB] = make_float2(is_pseudo ? -__builtin_inff() : e[r], is_pseudo ? pm : m);
-                        }
-                    }
-                    if (V == 64 && !preamble && lane == 0) {   // (with the preamble flag: written once, below)
-#pragma unroll
-                        for (int r = 0; r < kHalf; ++r) {
-                            const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), p.blank));
-                            ering[(r0 + r) * PB + PB - 1] = make_float2(-__builtin_inff(),
-                                                                        preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                        }
-                    }
-                };
-                // V == 32 (the common case): a lane moves four consecutive entries of a row with one
-                // dwordx4, eight lanes share a row, eight rows per pass -- two passes per half block.
-                const int vq = lane & 7, vr = lane >> 3;
-                float4 q0[2], q1[2];
-                auto issue4 = [&](int jb, float4 (&e)[2]) {
-                    if (jb < 0) return;
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
-                        int t = jb * kRows + 1 + r0 + ps * 8 + vr;
-                        t = t < T ? t : T - 1;
-                        e[ps] = *reinterpret_cast<const float4*>(seg_lpz + (int64_t)t * 32 + 4 * vq);
-                    }
-                };
-                auto put4 = [&](int jb, const float4 (&e)[2]) {
-                    if (jb < 0) return;
-                    const int bq = p.blank >> 2, bc = p.blank & 3;
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
-                        const float4 v = e[ps];
-                        const float own = bc == 0 ? v.x : bc == 1 ? v.y : bc == 2 ? v.z : v.w;
-                        const float lb = __shfl(own, (lane & ~7) | bq);     // the row's blank entry
-                        float2* row = ering + (r0 + ps * 8 + vr) * PB;
-                        row[4 * vq + 0] = make_float2(v.x, max3f(lb, v.x, kProbMax));
-                        row[4 * vq + 1] = make_float2(v.y, max3f(lb, v.y, kProbMax));
-                        row[4 * vq + 2] = make_float2(v.z, max3f(lb, v.z, kProbMax));
-                        row[4 * vq + 3] = make_float2(v.w, max3f(lb, v.w, kProbMax));
-                        if (vq == 0)  // start column: e = -inf, m = its stay step
-                            row[PB - 1] = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
-                    }
-                };
-                // set 0: blocks of jstart's parity, set 1: the others
-                auto run = [&](auto&& issue_f, auto&& put_f, auto& s0, auto& s1) {
-                    issue_f(jstart - 1, s1);
-                    put_f(jstart - 1, s1);
-                    issue_f(jstart - 3, s1);
-                    issue_f(jstart - 2, s0);
-                    auto step = [&](int j, auto& e) {
-                        lds_barrier();                              // A
-                        const int slow = sh_misc[3];
-                        lds_barrier();                              // B
-                        if (slow) lds_barrier();                    // F
-                        put_f(j - 2, e);
-                        issue_f(j - 4, e);
-                    };
-                    for (int j = jstart; j >= 0; j -= 2) {
-                        step(j, s0);
-                        if (j >= 1) step(j - 1, s1);
-                    }
-                };
-                // Under preamble_transition_cost_zero the start column's pseudo entry is the same (-inf, 0) in every
-                // row of every block: written once (64 entries leave no lane for it anyway)
-                if (preamble && lane < kHalf && !(PB == 33 && V == 32))
-                    ering[(r0 + lane) * PB + PB - 1] = make_float2(-__builtin_inff(), 0.0f);
-                if (PB == 33 && V == 32) run(issue4, put4, q0, q1);
-                else run(issue, put, e0, e1);
-                __builtin_amdgcn_s_setprio(0);
-            } else if (wave == 1) {
-                // ======== walker: one v_readlane + four scalar operations per row ====================
-                if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-                int x = 0;
-                for (int j = jstart; j >= 0; --j) {
-                    lds_barrier();                              // A
-                    const int slow = sh_misc[3];
-                    if (slow) {
-                        lds_barrier();                          // F: block j recomputed from its exact entry column
-                        x = 0;
-                    }
-                    const uint32_t W = wbuf[lane];
-                    const int pcj = sh_misc[2];
-                    lds_barrier();                              // B (waits for the two reads above)
-                    uint32_t S = 0u;
-                    int pidx = 0;
-#pragma unroll
-                    for (int i = 0; i < kRows; ++i) {
-                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W, x + pidx);
-                        S |= w & (1u << i);
-                        pidx += (int)((w >> i) & 1u);
-                    }
-                    if (lane == 0) {
-                        rec[j] = make_int2(pcj, (int)S);
-                        sh_misc[2] = pcj - pidx;                    // entry column of block j - 1
-                        sh_misc[3] = (pidx >= kRows && j >= 1) ? 1 : 0;
-                    }
-                    x = pidx;
-                    pc = pcj - pidx;
-                }
-                __builtin_amdgcn_s_setprio(0);
-                if (lane == 0) {
-                    sh_misc[0] = t_end;
-                    sh_misc[1] = (pc - shift > 0);  // reached t == 0 in a label column: the package's IndexError
-                }
-            } else {
-                // ======== wave 0: recompute =========================================================
-                if (p.flags & kBtFlagLowPriority) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-                const uint32_t* seg_bits = bits + sd.bits_off;
-                const bool preamble = (p.flags & 2u) != 0;
-                // m: the stay step the package's BACKTRACK assumes (max(blank, label)); mf: the one the FILL
-                // charged -- 0 in a column labelled blank under blank_transition_cost_zero, else m
-                const bool gratis = (p.flags & 1u) != 0;
-                auto cell = [&](float& prev, uint32_t& dec, float ee, float m, float mf) {
-                    const float pl = dpp_wave_shl1(prev);
-                    const float a = pl + ee;
-                    const float b = prev + mf;
-                    const float nw = max3f(a, b, kProbMax);
-                    const float rsw = ee - (nw - pl);
-                    const float rst = m - (nw - prev);
-                    // sign bit of (|rsw| - |rst|) == (|rst| > |rsw|): SWITCH; ties -> STAY
-                    const float d = __builtin_fabsf(rsw) - __builtin_fabsf(rst);
-                    dec = __builtin_amdgcn_alignbit(dec, __float_as_uint(d), 31);
-                    prev = nw;
-                    asm volatile("" : "+v"(dec));  // pin the row (see the fill kernel): no sinking of 32 rows' residuals
-                };
-                // slow path: block jb with lane 0 = column `top`, operands straight from global memory
-                auto rows_slow = [&](int jb, int top) -> uint32_t {
-                    const int col = top - lane;
-                    const int c = col - shift;
-                    float prev;
-                    if (jb == 0) prev = c <= 0 ? 0.0f : kProbMax;                     // table row 0
-                    else prev = col >= 0 ? __uint_as_float(seg_bits[(int64_t)(jb - 1) * p.Cpad + col]) : 0.0f;
-                    const int lab = c <= 0 ? -1 : (int)labs[c];
-                    float ee[kRows], lb[kRows];
-#pragma unroll
-                    for (int i = 0; i < kRows; ++i) {
-                        int t = jb * kRows + 1 + i;
-                        t = t < T ? t : T - 1;
-                        lb[i] = seg_lpz[(int64_t)t * V + p.blank];
-                        ee[i] = seg_lpz[(int64_t)t * V + (lab < 0 ? 0 : lab)];
-                    }
-                    uint32_t dec = 0u;
-#pragma unroll
-                    for (int i = 0; i < kRows; ++i) {
-                        const float e1 = lab < 0 ? -__builtin_inff() : ee[i];
-                        const float m = lab < 0 ? (preamble ? 0.0f : __builtin_fmaxf(lb[i], kProbMax))
-                                                : max3f(lb[i], ee[i], kProbMax);
-                        cell(prev, dec, e1, m, (gratis && lab == p.blank) ? 0.0f : m);   // (slow path: the select stays)
-                    }
-                    return c <= 0 ? 0u : dec;  // start column and left of it: STAY
-                };
-                {   // first block: exact entry column, rows after t_end are not part of the path
-                    const int b0 = 31 - ((t_end - 1) & 31);
-                    wbuf[lane] = rows_slow(jstart, pc) & ~((1u << b0) - 1u);
-                    if (lane == 0) {
-                        sh_misc[2] = pc;
-                        sh_misc[3] = 0;
-                    }
-                }
-                // Table row a block starts from = what the fill stored for the block before it,
-                // requested kDepth steps ahead for the 192 columns its lane 0 can still lie in and
-                // re-based on arrival.  (Branch-free and unconditional: a load under control flow
-                // makes the compiler wait for every outstanding load at the join; what must not be
-                // used is replaced on arrival.)
-#ifndef CTCFA_CK_DEPTH
-#define CTCFA_CK_DEPTH 2
-#endif
-                constexpr int kDepth = CTCFA_CK_DEPTH;
-                auto fetch = [&](int jb, int base, int part) -> uint32_t {  // start row of block jb
-                    const int col = base - 64 * part - lane;
-                    const uint32_t idx = (jb >= 1 && col >= 0) ? (uint32_t)((jb - 1) * p.Cpad + col) : 0u;  // < 2^31: one segment's words
-                    return seg_bits[idx];
-                };
-                uint32_t pf[kDepth][3];
-                int pbase[kDepth];
-                int j = jstart;
-#pragma unroll
-                for (int u = 0; u < kDepth; ++u) {
-                    pbase[u] = pc;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - u, pc, q);
-                }
-                while (j >= 0) {
-#pragma unroll
-                    for (int u = 0; u < kDepth; ++u) {
-                        if (j < 0) break;
-                        lds_barrier();                          // A
-                        if (sh_misc[3]) {                       // block j's words were computed for a window the path left
-                            wbuf[lane] = rows_slow(j, sh_misc[2]);
-                            lds_barrier();                      // F
-                        }
-                        const int pcj = sh_misc[2];             // entry column of block j = lane 0 of block j - 1
-                        const int src = (pbase[u] - pcj) + lane;  // 0 .. 191
-                        const uint32_t f0 = __shfl(pf[u][0], src & 63);
-                        const uint32_t f1 = __shfl(pf[u][1], src & 63);
-                        const uint32_t f2 = __shfl(pf[u][2], src & 63);
-                        float prev = __uint_as_float((src < 64) ? f0 : (src < 128) ? f1 : f2);
-                        const int col = pcj - lane;
-                        const int c = col - shift;                  // label column of this lane
-                        if (j == 1) prev = c <= 0 ? 0.0f : kProbMax;  // block 0 starts from table row 0
-                        if (col < 0) prev = 0.0f;                    // left of the padded table
-                        pbase[u] = pcj;
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) pf[u][q] = fetch(j - 1 - kDepth, pcj, q);
-                        const int lab = c <= 0 ? PB - 1 : (int)labs[c < C ? c : 0];  // c < C: the path never sits right of C-1
-                        const float2* erow = ering + lab;
-                        float2 emr[kRows];
-#pragma unroll
-                        for (int i = 0; i < kRows; ++i) emr[i] = erow[i * PB];
-                        lds_barrier();                          // B (waits for the reads above)
-                        if (j >= 1) {
-                            uint32_t dec = 0u;
-                            if (!gratis) {   // (uniform: no select per row when the flag is off)
-#pragma unroll
-                                for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y, emr[i].y);
-                            } else {
-                                const bool free_stay = lab == p.blank;
-#pragma unroll
-                                for (int i = 0; i < kRows; ++i) cell(prev, dec, emr[i].x, emr[i].y, free_stay ? 0.0f : emr[i].y);
-                            }
-                            wbuf[lane] = c <= 0 ? 0u : dec;
-                        }
-                        --j;
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-            }
-        } else if (wave == 1 && lane == 0) {
-            sh_misc[0] = t_end;
-            sh_misc[1] = (pc - shift > 0);
-        }
-    } else
     // ---- phase A (wave 0): the walk, one scalar step per run of STAYs ----------------------
     if (wave == 0) {
         float bv = red_v[0];
@@ -1903,15 +1537,14 @@ struct WaveSync {  // one wave: program order + completed memory operations is a
     }
 };
 
-template <int PB>  // 0: decision words from the fill; 33 / 65: checkpoint mode, V <= 32 / V <= 64
-__global__ void __launch_bounds__(kBtThreads, 5)   // <= 96 VGPRs (it wants 97): two backtrack workgroups still fit a SIMD that carries five 64-register fill tiles
+__global__ void __launch_bounds__(kBtThreads, 5)   // <= 96 VGPRs: two backtrack workgroups still fit a SIMD that carries five 64-register fill tiles
 backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_v[kBtThreads / 64];
     __shared__ int red_t[kBtThreads / 64];
-    __shared__ int sh_misc[4];  // [0] t_end, [1] bad; checkpoint mode: [2] entry column of the block to walk, [3] slow-path flag
+    __shared__ int sh_misc[4];  // [0] t_end, [1] bad
     const SegDesc sd = a.segs[blockIdx.x];
-    backtrack_body<kBtThreads, PB>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
+    backtrack_body<kBtThreads>(a, sd, (int)threadIdx.x, smem, red_v, red_t, sh_misc, BlockSync(), NoTick());
 }
 
 
@@ -1975,7 +1608,7 @@ stride_backtrack_kernel(BtArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = (blockDim.x >> 6) - p.scorers;   // striders: waves 0 .. NW-1 (the waves after them only score)
     const int nthreads = blockDim.x;
-    const int ferr = a.fill_err ? *a.fill_err : 0;   // (asked for first: nothing else waits behind it)
+    const bool ferr = a.fill_err ? *a.fill_err == a.fill_run : false;   // (asked for first: nothing else waits behind it)
     const int T = sd.T, C = sd.C, U = sd.U, shift = sd.shift, V = p.V;
     const float* __restrict__ seg_lpz = a.lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = a.labels + sd.lab_off;

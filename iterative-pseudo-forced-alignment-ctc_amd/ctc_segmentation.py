@@ -208,7 +208,9 @@ def _align_label_matrices(engine, config, lpz_list, labels, utt_begin_list, want
     return engine.align_batch(config.to_native(), lpz_list, mats, utt_begin_list, want_state=want_state, label_width=S)
 
 
-def _raise_for_status(status):
+def _raise_for_status(status, error=None):
+    if error is not None:
+        raise error
     if status == _native.ST_AUDIO_SHORTER_THAN_TEXT:
         raise AssertionError("Audio is shorter than text!")
     if status == _native.ST_BACKTRACK_FAILED:
@@ -216,7 +218,8 @@ def _raise_for_status(status):
     if status == _native.ST_WINDOWED_UNSUPPORTED:
         raise NotImplementedError("windowed DP regime with more than ~40 000 frames (one column must fit the LDS)")
     if status == _native.ST_TEXT_TOO_LONG:
-        raise NotImplementedError("more label columns than one workgroup of the fill kernel covers (~5 400)")
+        raise NotImplementedError("more label columns than one workgroup of the fill kernel covers "
+                                  "(ctcfa_max_label_columns: 5 485 for a 32-entry vocabulary, 5 119 for the others up to 128)")
     if status != _native.ST_OK:
         raise RuntimeError(f"ctcfa status {status}")
 
@@ -225,31 +228,58 @@ def _is_device_tensor(x):
     return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
 
-def _validate_segments(lpz_list, labels, utt_begin_list):
-    """What NumPy would have refused in the package, refused before anything reaches the kernels
-    (they index emissions with the raw label): label ids outside the vocabulary, emissions of
-    different vocabulary sizes in one batch, utterance starts outside the label sequence."""
+ST_INVALID_INPUT = -1   # (Python side only) the segment's inputs were refused on the host: the result dict carries "error"
+
+
+def _segment_errors(lpz_list, labels, utt_begin_list):
+    """Per segment: the exception NumPy would have answered with in the package (label ids outside the
+    vocabulary, utterance starts outside the label sequence, ...) or None -- the kernels index emissions with
+    the raw label, so such a segment never reaches them -- and whether its label sequence holds a -1 after the
+    first entry (a column without a token: the package skips it; served by the label-matrix kernel)."""
+    errors, minus_one = [None] * len(lpz_list), [False] * len(lpz_list)
     if not lpz_list:
-        return
+        return errors, minus_one
     V = int(lpz_list[0].shape[1])
     for b, (l, g) in enumerate(zip(lpz_list, labels)):
         if l.ndim != 2 or int(l.shape[1]) != V:
-            raise ValueError(f"segment {b}: emissions must be [T, {V}] like the first segment's, got {tuple(l.shape)}")
-        if len(g) < 2 or g[0] != -1:
-            raise ValueError(f"segment {b}: ground truth must start with -1 and hold at least one more label")
-        # (one pass: as unsigned numbers, negative ids are far above any vocabulary)
-        if int(g[1:].view(np.uint32).max()) >= V:
-            raise IndexError(f"segment {b}: label id outside the vocabulary [0, {V})")
+            errors[b] = ValueError(f"segment {b}: emissions must be [T, {V}] like the first segment's, got {tuple(l.shape)}")
+        elif len(g) < 2 or g[0] != -1:
+            errors[b] = ValueError(f"segment {b}: ground truth must start with -1 and hold at least one more label")
+        else:
+            inner = g[1:]
+            minus_one[b] = bool((inner == -1).any())
+            # (one pass: as unsigned numbers, negative ids are far above any vocabulary)
+            rest = inner[inner != -1] if minus_one[b] else inner
+            if len(rest) and int(rest.view(np.uint32).max()) >= V:
+                errors[b] = IndexError(f"segment {b}: label id outside the vocabulary [0, {V})")
     if utt_begin_list is not None:
         for b, (u, g) in enumerate(zip(utt_begin_list, labels)):
+            if errors[b] is not None:
+                continue
             if getattr(u, "ndim", 1) != 1 or len(u) < 1:
-                raise ValueError(f"segment {b}: utt_begin_indices must hold U + 1 indices")
+                errors[b] = ValueError(f"segment {b}: utt_begin_indices must hold U + 1 indices")
+                continue
             ul = u.tolist() if hasattr(u, "tolist") else list(u)
             C = len(g)
             # determine_utterance_segments reads timings[i-1], timings[i], timings[i+1] for every start i
             # and timings[e-1], timings[e] for the closing index e
             if len(ul) > 1 and (min(ul[:-1]) < 1 or max(ul[:-1]) > C - 2 or ul[-1] < 1 or ul[-1] > C - 1):
-                raise IndexError(f"segment {b}: utterance start outside the label sequence (C = {C})")
+                errors[b] = IndexError(f"segment {b}: utterance start outside the label sequence (C = {C})")
+    return errors, minus_one
+
+
+def _validate_segments(lpz_list, labels, utt_begin_list):
+    """Raise the first of ``_segment_errors`` (callers that hand over ONE launch's worth of trusted shapes)."""
+    for e in _segment_errors(lpz_list, labels, utt_begin_list)[0]:
+        if e is not None:
+            raise e
+
+
+def _refused(error, T, C, U):
+    """Result dict of a segment that was refused on the host (the other segments of the call are aligned)."""
+    return {"status": ST_INVALID_INPUT, "error": error, "t_end": -1, "frame_of_label": np.zeros(C, np.int32),
+            "char_prob": np.zeros(T, np.float32), "state": np.full(T, -2, np.int32),
+            "seg_start": np.zeros(U), "seg_end": np.zeros(U), "seg_score": np.zeros(U)}
 
 
 def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, engine=None, want_state=True):
@@ -267,7 +297,28 @@ def get_segments_device(config, lpz_list, ground_truth_list, utt_begin_list, eng
     labels = [_labels_from_mat(g) for g in ground_truth_list]
     if any(g.ndim == 2 for g in labels):
         return _align_label_matrices(engine, config, lpz_list, labels, utt_begin_list, want_state)
-    _validate_segments(lpz_list, labels, utt_begin_list)
+    errors, minus_one = _segment_errors(lpz_list, labels, utt_begin_list)
+    if any(e is not None for e in errors) or any(minus_one):
+        # one refused segment is that segment's error, not the launch's; a sequence with a -1 inside goes through
+        # the label-matrix kernel (as a [C, 1] matrix), the rest as usual
+        out = [None] * len(lpz_list)
+        for b, e in enumerate(errors):
+            if e is not None:
+                U = 0 if utt_begin_list is None else max(0, len(utt_begin_list[b]) - 1)
+                out[b] = _refused(e, int(lpz_list[b].shape[0]) if getattr(lpz_list[b], "ndim", 0) >= 1 else 0, len(labels[b]), U)
+        for pick in ([b for b in range(len(out)) if out[b] is None and not minus_one[b]],
+                     [b for b in range(len(out)) if out[b] is None and minus_one[b]]):
+            if not pick:
+                continue
+            sub_gt = [labels[b].reshape(-1, 1) if minus_one[b] else labels[b] for b in pick]
+            sub_ub = None if utt_begin_list is None else [utt_begin_list[b] for b in pick]
+            if minus_one[pick[0]]:
+                part = _align_label_matrices(engine, config, [lpz_list[b] for b in pick], sub_gt, sub_ub, want_state)
+            else:
+                part = get_segments_device(config, [lpz_list[b] for b in pick], sub_gt, sub_ub, engine=engine, want_state=want_state)
+            for b, r in zip(pick, part):
+                out[b] = r
+        return out
     emission_of = shared_emissions(lpz_list)
     if lpz_list and all(_is_device_tensor(l) for l in lpz_list):
         return _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state, emission_of)
@@ -312,7 +363,7 @@ def _align_resident(engine, config, lpz_list, labels, utt_begin_list, want_state
 def ctc_segmentation(config, lpz, ground_truth, engine=None):
     """Fill + backtrack for one segment -> (timings fp64 [C], char_probs fp64 [T], state_list)."""
     res = get_segments_device(config, [lpz], [ground_truth], None, engine=engine)[0]
-    _raise_for_status(res["status"])
+    _raise_for_status(res["status"], res.get("error"))
     timings = res["frame_of_label"].astype(np.int64) * config.index_duration_in_seconds
     return timings, res["char_prob"].astype(np.float64), state_list_from(config, res["state"])
 

@@ -131,6 +131,12 @@ def test_inputs_numpy_would_refuse_are_refused_on_the_host(pkg):
         cs._validate_segments([lpz], [good], [np.array([1, 4, 4])])                      # trailing empty utterance
     with pytest.raises(IndexError):
         cs._validate_segments([lpz], [good], [np.array([0, 4])])                         # start column as an utterance start
+    # per segment: one refused segment is its own error, not the launch's; a -1 inside a sequence is no error
+    # (the package skips such a column: served by the label-matrix kernel)
+    errors, minus_one = cs._segment_errors([lpz, lpz, lpz], [good, np.array([-1, 0, 8, 0], np.int32), np.array([-1, 0, -1, 3, 0], np.int32)],
+                                           [np.array([1, 4]), np.array([1, 3]), np.array([1, 4])])
+    assert errors[0] is None and isinstance(errors[1], IndexError) and errors[2] is None
+    assert minus_one == [False, False, True]
 
 
 def test_every_task_keeps_its_own_timing_config(pkg):

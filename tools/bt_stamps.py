@@ -1,6 +1,6 @@
 """Diagnostic only: per-wave cycle totals a -DCTCFA_BT_STAMP build of the checkpoint-mode backtrack
 (stride_backtrack_kernel) leaves in the caller's `state` buffer.
-    tools/build_variant.sh btstamp -DCTCFA_BT_STAMP && CTCFA_LIB=$PWD/variants/btstamp.so python tools/bt_stamps.py"""
+    tools/build_variant.sh btstamp -DCTCFA_BT_STAMP && CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=$PWD/variants/btstamp.so python tools/bt_stamps.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Tuning builds of libctcfa_hip.so from the current sources with extra -D macros (one vocabulary pitch:
-# compiles in ~25 s).  Load one with CTCFA_LIB=$PWD/variants/<name>.so.
+# compiles in ~25 s).  Load one with CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=$PWD/variants/<name>.so (the binding refuses tuning
+# builds otherwise: ctcfa_build_flags()).
 #   tools/build_variant.sh stamp3 -DCTCFA_STAMP=3        per-tile cycle stamps (tools/stamps2.py)
 #   tools/build_variant.sh abl2 -DCTCFA_ABL=2            group hand-over partly left out (WRONG results, timing only)
-#   tools/build_variant.sh prio1 -DCTCFA_TILE_PRIO=1     tile priorities; also CTCFA_PRODUCER_PRIO, CTCFA_PF,
-#                                                        CTCFA_POLL_LEAD, CTCFA_PEEK_LEAD, CTCFA_NBR_SLEEP, CTCFA_VGPR_CAP,
-#                                                        CTCFA_NO_DEADZONE, CTCFA_DEBUG_SPIN, CTCFA_CK_DEPTH
+#   tools/build_variant.sh btstamp -DCTCFA_BT_STAMP      cycle stamps of the checkpoint-mode backtrack (tools/bt_stamps.py)
+#   tools/build_variant.sh pf3 -DCTCFA_PF=3              also CTCFA_PRODUCER_PRIO, CTCFA_POLL_LEAD, CTCFA_PEEK_LEAD, CTCFA_NBR_SLEEP,
+#                                                        CTCFA_VGPR_CAP, CTCFA_NO_DEADZONE, CTCFA_DEBUG_SPIN, CTCFA_TRACE_NT,
+#                                                        CTCFA_SB_RING, CTCFA_SB_MARGIN
 #   tools/build_variant.sh all                           stamp3 + abl0..4 (what tools/fill_cycles.sh needs)
 set -e
 cd "$(dirname "$0")/.."

@@ -1,7 +1,7 @@
 """Diagnostic only: per-tile cycle totals an instrumented build (-DCTCFA_STAMP) leaves in the lastcol
 workspace: total, waiting for the left neighbour, waiting for staged emissions, and (CTCFA_STAMP=3) a stamp
 every 8 rows of block 40.  Such a build passes the caller's char_prob buffer as the stamp buffer and skips
-the backtrack (tools/build_variant.sh stamp3 -DCTCFA_STAMP=3; CTCFA_LIB=variants/stamp3.so)."""
+the backtrack (tools/build_variant.sh stamp3 -DCTCFA_STAMP=3; CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=variants/stamp3.so)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

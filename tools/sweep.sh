@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/sweep.sh "<lib list>" "<K list>"   -> one line per (lib, K)
 for L in $1; do for K in $2; do
-  CTCFA_LIB=$PWD/$L timeout -k 10 200 python bench.py --steps 300 --warmup 20 --cpu-sample 0 --cols-per-lane $K $SWEEP_FLAGS > gpurun_out/sw.json 2> gpurun_out/sw.err
+  CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=$PWD/$L timeout -k 10 200 python bench.py --steps 300 --warmup 20 --cpu-sample 0 --cols-per-lane $K $SWEEP_FLAGS > gpurun_out/sw.json 2> gpurun_out/sw.err
   python - "$L" "$K" <<'PY'
 import json,sys
 try:
