@@ -62,7 +62,7 @@ def parse():
                     help="untimed passes of the same step before the warm-up steps (~0.25 s), so that the timed "
                          "region sees the card's sustained clocks and not the ramp from idle (0 = off)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of segment boundaries")
-    ap.add_argument("--gather-every", type=int, default=16,
+    ap.add_argument("--gather-every", type=int, default=64,
                     help="N > 1: segment boundaries of this many steps travel in one all-gather "
                          "(fewer, larger collectives; every step's results are still gathered inside the timed region)")
     ap.add_argument("--timing-stride", type=int, default=0,
@@ -440,9 +440,13 @@ def main():
         return run_grouped(args, pkg, torch, rank, world, local_rank, rehearsal, cpu)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # CTCFA_BENCH_FORCE_DIST=1 (not used by the driver): the collective path with a process group of ONE rank -- the
+    # RCCL calls of the N > 1 schedule on a one-GPU box
+    use_dist = world > 1 or os.environ.get("CTCFA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -477,11 +481,11 @@ def main():
     # one being filled, one whose last steps are still in flight, one being gathered.
     G = max(1, args.gather_every)
     seg_ring = [torch.empty(G, 3, B * U, dtype=torch.float64, device=dev) for _ in range(3)]
-    gathered = torch.empty(world, G, 3, B * U, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty(world, G, 3, B * U, dtype=torch.float64, device=dev) if use_dist else None
     stream = torch.cuda.current_stream()
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if use_dist else None
     pipelined = not args.serial
-    do_gather = world > 1 and not args.no_gather
+    do_gather = use_dist and not args.no_gather
     n_calls = [0]
     n_gathered = [0]   # groups handed to the collective so far
 
@@ -529,7 +533,7 @@ def main():
             stream.wait_stream(comm)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -561,7 +565,7 @@ def main():
     drain()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -611,7 +615,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
