@@ -10,12 +10,46 @@ functions here give the DP results support that is independent of that restateme
 * ``path_from_result``: the path a result (frame_of_label, t_end) describes, and its exact cost;
 * ``sequential_fp32_sum``: the sum of char_probs along the returned path, accumulated in fp32 in
   frame order -- what the fill computed for table[t_end, C-1] if the path is the one it took.
+* ``utterance_segments``: SURVEY Appendix A.4 (determine_utterance_segments) written out with NumPy's own
+  ``mean`` -- the function the package calls -- from a result's frame_of_label / char_prob: the boundaries and
+  scores of a result are checked without going through oracle/ at all (its pairwise-summation restatement
+  included).
 """
 import itertools
 
 import numpy as np
 
 NEG = -1e9
+
+
+def utterance_segments(frame_of_label, char_prob, utt_begin, index_duration, n=30):
+    """-> (start[U], end[U], score[U]) in float64, straight from Appendix A.4: timings = frame x index_duration;
+    boundaries between the neighbouring labels' timings, clamped to +-0.5 s; score = the minimum over the
+    sliding means of ``n`` frames of char_probs (np.mean), or the plain mean of a shorter span."""
+    timings = np.asarray(frame_of_label, np.int64).astype(np.float64) * float(index_duration)
+    cp = np.asarray(char_prob, np.float32).astype(np.float64)
+
+    def compute_time(i, kind):
+        middle = (timings[i] + timings[i - 1]) / 2
+        return max(timings[i + 1] - 0.5, middle) if kind == "begin" else min(timings[i - 1] + 0.5, middle)
+
+    starts, ends, scores = [], [], []
+    ub = [int(u) for u in utt_begin]
+    for u in range(len(ub) - 1):
+        start, end = compute_time(ub[u], "begin"), compute_time(ub[u + 1], "end")
+        start_t, end_t = int(round(start / index_duration)), int(round(end / index_duration))
+        if end_t <= start_t:
+            score = -10000000000.0
+        elif end_t - start_t <= n:
+            score = float(np.mean(cp[start_t:end_t]))
+        else:
+            score = 0.0
+            for t in range(start_t, end_t - n):
+                score = min(score, float(np.mean(cp[t:t + n])))
+        starts.append(start)
+        ends.append(end)
+        scores.append(score)
+    return np.asarray(starts), np.asarray(ends), np.asarray(scores)
 
 
 def step_costs(lpz, gt, blank=0, preamble=True):

@@ -6,6 +6,8 @@ char_prob values are fp32 emissions copied out, so they are compared exactly too
 import numpy as np
 import pytest
 
+from tests import independent
+
 pytestmark = pytest.mark.gpu
 
 SCORE_TOL = 1e-4  # the tolerance north_star states for log-prob confidence scores
@@ -37,6 +39,12 @@ def _check(pkg, oracle, segs, res, cfg_kw=None):
         assert np.array_equal(r["seg_start"], o["seg_start"]), i
         assert np.array_equal(r["seg_end"], o["seg_end"]), i
         np.testing.assert_allclose(r["seg_score"], o["seg_score"], rtol=0, atol=SCORE_TOL)
+        # ... and, without oracle/: Appendix A.4 with NumPy's own mean on the HIP path's own frames and char_probs
+        if len(ub) > 1:
+            st, en, sc = independent.utterance_segments(r["frame_of_label"], r["char_prob"], ub, DUR,
+                                                        n=(cfg_kw or {}).get("score_min_mean_over_L", 30))
+            assert np.array_equal(r["seg_start"], st) and np.array_equal(r["seg_end"], en), f"segment {i}: boundaries vs A.4"
+            np.testing.assert_allclose(r["seg_score"], sc, rtol=0, atol=1e-12, err_msg=f"segment {i}: scores vs A.4 (np.mean)")
 
 
 def _run(pkg, segs, **cfg):

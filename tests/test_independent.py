@@ -79,3 +79,55 @@ def test_hip_char_probs_sum_to_the_oracle_table_value(pkg, oracle):
         assert r["t_end"] == t_end
         got = ind.sequential_fp32_sum(r["char_prob"], t_end, first=int(r["frame_of_label"][1]))
         assert got == pytest.approx(float(table[t_end, len(gt) - 1]), rel=2e-6, abs=1e-4)
+
+
+def test_oracle_scoring_is_appendix_a4_with_numpys_own_mean(oracle, pkg):
+    """determine_utterance_segments: the oracle's boundaries and scores (its restated pairwise summation
+    included) against Appendix A.4 written with np.mean itself, on the oracle's own frames and char_probs."""
+    syn = pkg.synthetic
+    for L in (30, 7, 64):
+        cfg = oracle.make_config(index_duration=0.0200298, score_min_mean_over_L=L)
+        for s, (T, U, n) in enumerate([(300, 3, 20), (499, 4, 24), (150, 2, 12), (700, 6, 28), (1200, 10, 25), (64, 1, 10)]):
+            lpz, gt, ub = syn.make_segment(5000 + s, T, 32, U, n)
+            o = oracle.get_segments(lpz, gt, ub, cfg)
+            st, en, sc = ind.utterance_segments(o["frame_of_label"], o["char_probs"], ub, 0.0200298, n=L)
+            assert np.array_equal(o["seg_start"], st) and np.array_equal(o["seg_end"], en)
+            np.testing.assert_allclose(o["seg_score"], sc, rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_windowed_regime_never_beats_and_mostly_attains_the_brute_force_optimum(pkg):
+    """The windowed regime (T > min_window_size: per-column windows of W rows that follow the running argmax)
+    without the restatement, on grid cases with min_window_size 4..8 < T.  The package's windowed backtrack may
+    leave its table (negative NumPy indices wrap around) and then describes no monotone path at all; whenever the
+    result IS a monotone path through the trellis -- the frames it visited are the ones whose state is set -- no
+    enumeration beats its exact cost, and in most cases (the window did not cut the optimum off) its cost is the
+    enumerated maximum over the paths that end where it ends."""
+    rng = np.random.default_rng(909)
+    legal = attained = total = 0
+    for m in (4, 5, 6, 7, 8):
+        cases = []
+        while len(cases) < 40:
+            C = int(rng.integers(2, 6))
+            T = int(rng.integers(max(C, m + 1), 10))
+            cases.append(ind.grid_case(rng, T, C, 4))
+        config = pkg.CtcSegmentationParameters(index_duration=0.02, min_window_size=m)
+        res = pkg.ctc_segmentation.get_segments_device(config, [c[0] for c in cases], [c[1] for c in cases], None)
+        for (lpz, gt), r in zip(cases, res):
+            if r["status"] != 0:
+                assert r["status"] == 2   # the package's IndexError after the last window doubling
+                continue
+            total += 1
+            visited = np.nonzero(np.asarray(r["state"]) != -2)[0]
+            if len(visited) == 0:
+                continue
+            t_last = int(visited.max())
+            best, _ = ind.brute_force_optimum(lpz, gt)
+            try:
+                cost = ind.path_from_result(lpz, gt, r["frame_of_label"], t_last)
+            except AssertionError:
+                continue   # not a monotone path: index wrap-around (nothing to compare with)
+            legal += 1
+            assert best[t_last] is not None and cost <= best[t_last]
+            attained += cost == best[t_last]
+    assert total >= 150 and legal >= 0.6 * total and attained >= 0.7 * legal, (total, legal, attained)
