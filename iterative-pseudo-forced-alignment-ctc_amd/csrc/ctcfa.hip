@@ -403,7 +403,7 @@ int ctcfa_build_flags(void) {
     f |= CTCFA_BUILD_ONE_PITCH;
 #endif
 #if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_PEEK_LEAD != 3 || \
-    CTCFA_NBR_SLEEP != 1 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 0 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
+    CTCFA_NBR_SLEEP != 1 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
     f |= CTCFA_BUILD_RETUNED;
 #endif
     return f;

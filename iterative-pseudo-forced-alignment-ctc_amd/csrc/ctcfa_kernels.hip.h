@@ -48,7 +48,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #ifndef CTCFA_PRODUCER_PRIO
-#define CTCFA_PRODUCER_PRIO 0
+#define CTCFA_PRODUCER_PRIO 1   // above the backtrack waves of the previous batch (priority 0), below the tiles
+#endif
+#ifndef CTCFA_TILE_PRIO_BASE
+#define CTCFA_TILE_PRIO_BASE 2   // earlier half of a segment's tiles; the later half runs one above
 #endif
 #ifndef CTCFA_VGPR_CAP
 #define CTCFA_VGPR_CAP 1
@@ -651,9 +654,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // Tiles of one SIMD compete for issue slots by priority, then age: the later-dispatched waves
     // would always lose.  A tile is only ever waited for by its right neighbour, so the left ones go first.
     // Shipped: the later half of the tiles first (measured on config 3, round 2: earlier tiles first 160 us, later
-    // half first 148, producer above the tiles 165-170, "a tile that had to wait steps back" 155).
-    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(1);
+    // half first 148, producer above the tiles 165-170, "a tile that had to wait steps back" 155).  Round 3: tiles
+    // 3 / 2, producers 1 -- one above the striders of the previous batch's backtrack (priority 0), which otherwise
+    // share the producers' level: 0.1559 -> 0.1542 ms per pipelined step, the fill alone unchanged.
+    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(CTCFA_TILE_PRIO_BASE + 1);
+    else __builtin_amdgcn_s_setprio(CTCFA_TILE_PRIO_BASE);
 
     // Dead zone: column c cannot reach the end cell's column C-1 from rows t > T-C+c, so the
     // backtrack never visits those cells and they feed only other dead cells (in this tile or, through
