@@ -1763,9 +1763,19 @@ stride_backtrack_kernel(BtArgs a) {
         float4 stg[NQ];
         int stg_n0 = 0;   // first element (of the segment's lpz) of the block in stg[]
         const int nmax = T * V - 4 > 0 ? T * V - 4 : 0;   // last place a dwordx4 load may start
-        auto issue = [&](int jb) {
+        bool stg_blank_only = false;   // the block in stg[] lies in the start column: only its blank entries were asked for
+        auto issue = [&](int jb, bool blank_only = false) {
             const int n0 = (jb * kRows + 1) * V;
             stg_n0 = n0;
+            stg_blank_only = blank_only;
+            if (blank_only) {
+                // the path sits in column 0 from here to the first frame: nothing to recompute, and the per-frame
+                // outputs of such a block need the blank posterior of its 32 frames, not its 32 V emissions
+                int t = jb * kRows + 1 + (lane & 31);
+                t = t < T ? t : T - 1;
+                stg[0].x = seg_lpz[t * V + p.blank];
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 int n = n0 + 4 * (lane + 64 * q);
@@ -1775,6 +1785,10 @@ stride_backtrack_kernel(BtArgs a) {
             }
         };
         auto put = [&]() {
+            if (stg_blank_only) {
+                if (lane < kRows) *reinterpret_cast<float*>(smem + my_slot + (uint32_t)((lane * P + p.blank) * 4)) = stg[0].x;
+                return;
+            }
             if (V == P) {
                 // (rows past the end of the segment hold its last entries: nobody reads what becomes of them)
 #pragma unroll
@@ -1895,7 +1909,6 @@ stride_backtrack_kernel(BtArgs a) {
 #endif
         for (; j >= 0; j -= NW) {
             SB_COUNT(13);
-            if (j - NW >= 0) issue(j - NW);   // my next block's rows: a whole turn in flight
             // ---- anchor: the nearest block above whose entry column is known ----
             int top, d, top_anchor = 0;
             {
@@ -1956,6 +1969,7 @@ stride_backtrack_kernel(BtArgs a) {
             const int ilast = (j == jstart) ? ((t_end - 1) & 31) : kRows - 1;
             const int anchorE = top_anchor;
             const bool in_start_column = anchorE - shift <= 0;   // the path has reached column 0: it stays there, frame by frame
+            if (j - NW >= 0) issue(j - NW, in_start_column);   // my next block's rows: a whole turn in flight
             SB_LAP(6);    // anchor
             if (in_start_column) {
                 top = anchorE;   // == this block's entry column: no recurrence to run, no SWITCH to find
