@@ -282,16 +282,19 @@ def _emissions(aligner, waveforms, batch_lpz, frames_fn=None):
 
 
 def word_hits(asr_model, aligner, records, indices, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
-              right_offset=0.0, log=None, rows_per_launch=2048, number_to_words=None, batch_lpz=False, frames_fn=None):
+              right_offset=0.0, log=None, rows_per_launch=2048, number_to_words=None, batch_lpz=False, frames_fn=None,
+              return_stop=False):
     """Row loop of word_level_alignment.main (:35-135) over ``records[i] for i in indices`` ->
     fixed-width records ``(i, clip_start, start, end, score)``: what a rank hands to the gather.
 
     Rows go through in chunks of ``rows_per_launch``: load and normalise the clips, encode them, align the
     chunk in ONE launch, keep the records, drop the audio -- a rank never holds more than a chunk of waveforms
-    (10 000 rows of a few seconds each are gigabytes)."""
+    (10 000 rows of a few seconds each are gigabytes).
+    ``return_stop``: also return the row at which an unreadable clip ended the run (None: none did) -- the
+    reference stops there for good (:63-66); a sharded run drops every hit from that row on (``word_main``)."""
     log = log or (lambda m: None)
     indices = list(indices)
-    out, stopped = [], False
+    out, stopped, stop_row = [], False, None
     for k in range(0, len(indices), rows_per_launch):
         chunk = []
         for i in indices[k:k + rows_per_launch]:
@@ -310,7 +313,7 @@ def word_hits(asr_model, aligner, records, indices, opener=WavFile, time_info=Tr
             except Exception:
                 print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
                 print("Ending execution as non-valid audio file has been provided.")
-                stopped = True
+                stopped, stop_row = True, i
                 break   # the reference stops the whole run here (:63-66); the rows before it are aligned
             text = sentence_pieces(text_prep.normalize_transcript(row["Normalized_Transcription"], number_to_words).upper(),
                                    row["Wanted_Text"])
@@ -337,7 +340,7 @@ def word_hits(asr_model, aligner, records, indices, opener=WavFile, time_info=Tr
         del chunk, lpzs, tasks   # the clips and emissions of this chunk are not needed again
         if stopped:
             break
-    return out
+    return (out, stop_row) if return_stop else out
 
 
 def align_words(asr_model, aligner, df, opener=WavFile, time_info=True, offset_time=0.0, left_offset=0.0,
@@ -374,7 +377,7 @@ def search_hits(asr_model, aligner, records, indices, wanted_text, opener=WavFil
     log = log or (lambda m: None)
     query = "·" + wanted_text.strip() + "·"
     indices = list(indices)
-    out, waveform = [], None
+    out, waveform, last_loaded = [], None, None
     for k in range(0, len(indices), rows_per_launch):
         chunk = []
         for i in indices[k:k + rows_per_launch]:
@@ -386,6 +389,23 @@ def search_hits(asr_model, aligner, records, indices, wanted_text, opener=WavFil
                 waveform = asr_model.audio_normalizer(clip, sr)
             except Exception:   # the reference prints and goes on with the previous row's audio (:66-67)
                 print("Start frame: {0}. Enf frame: {1}. Row: {2}".format(clip_start, clip_end, row))
+                if last_loaded != i - 1:
+                    # "the previous row" is the previous row of the TABLE -- in a sharded run not the row this rank
+                    # aligned before: the clip of the nearest earlier row that can be read
+                    waveform = None
+                    for k in range(i - 1, -1, -1):
+                        try:
+                            prev = records[k]
+                            src = opener(prev["Sample_Path"])
+                            ps, pe = float(prev["Start"]), float(prev["End"])
+                            clip, sr = src.load(int(ps * src.sample_rate), int((pe - ps) * src.sample_rate))
+                            waveform = asr_model.audio_normalizer(clip, sr)
+                            break
+                        except Exception:
+                            continue
+            last_loaded = i
+            if waveform is None:   # (the reference has no audio at all at this point and fails)
+                raise RuntimeError("row {0}: no readable audio at or before this row".format(i))
             chunk.append((i, row, clip_start, clip_end, waveform))
         lpzs = _emissions(aligner, [c[4] for c in chunk], batch_lpz, frames_fn)
         tasks = [aligner.prepare_segmentation_task(query, lpz, row["Sample_ID"], wf.shape[0])
@@ -489,19 +509,32 @@ def _row_costs(records):
     return costs
 
 
-def _gather_hits(dist, hits, world):
+def _gather_hits(dist, hits, world, stop_row=None, error=None):
     """Every rank's (row, clip_start, start, end, score) records -> all of them, in row order (the
-    single exchange of the row-level stages; role of src/postprocess/merge_aligned_files.py:17-25)."""
+    single exchange of the row-level stages; role of src/postprocess/merge_aligned_files.py:17-25).
+    ``stop_row``: the row at which this rank's run ended for good (word level: an unreadable clip) -- hits from the
+    smallest such row on are dropped, as the reference's single process never reaches them.  ``error``: an
+    exception this rank ran into; it still takes part in the collective (nobody is left waiting) and every rank
+    raises afterwards."""
     if dist is None:
-        return sorted(hits, key=lambda h: h[0])
+        if error is not None:
+            raise error
+        return sorted(h for h in hits if stop_row is None or h[0] < stop_row)
     import torch
 
     from . import sharding
     on_gpu = dist.get_backend() == "nccl"
     local = torch.tensor(hits, dtype=torch.float64).reshape(-1, 5)
+    note = torch.tensor([[float("inf") if stop_row is None else float(stop_row), 1.0 if error is not None else 0.0]],
+                        dtype=torch.float64)
     if on_gpu:
-        local = local.cuda()
-    return [tuple(r) for r in sharding.merge_in_unit_order(sharding.gather_records(local, dist), None)]
+        local, note = local.cuda(), note.cuda()
+    notes = torch.cat([n.cpu() for n in sharding.gather_records(note, dist)])
+    rows = sharding.merge_in_unit_order(sharding.gather_records(local, dist), None)
+    if bool((notes[:, 1] > 0).any()):
+        raise error if error is not None else RuntimeError("another rank failed in the row stage (see its log)")
+    stop = float(notes[:, 0].min())
+    return [tuple(r) for r in rows if r[0] < stop]
 
 
 def utterance_parser():
@@ -596,10 +629,15 @@ def word_main(args, asr_model=None, aligner=None, opener=WavFile, number_to_word
         if args.logs_path else None
     records = read_tsv(args.tsv_path).to_dict(orient="records")
     mine = sharding.assign_units(_row_costs(records), world)[rank]
-    hits = word_hits(asr_model, aligner, records, mine, opener, args.time_info, args.offset_time, args.left_offset,
-                     args.right_offset, log, rows_per_launch=max(1, int(getattr(args, "rows_per_launch", 2048))),
-                     number_to_words=number_to_words, batch_lpz=bool(getattr(args, "batch_lpz", False)))
-    hits = _gather_hits(dist, hits, world)
+    hits, stop_row, error = [], None, None
+    try:
+        hits, stop_row = word_hits(asr_model, aligner, records, mine, opener, args.time_info, args.offset_time, args.left_offset,
+                                   args.right_offset, log, rows_per_launch=max(1, int(getattr(args, "rows_per_launch", 2048))),
+                                   number_to_words=number_to_words, batch_lpz=bool(getattr(args, "batch_lpz", False)),
+                                   return_stop=True)
+    except Exception as exc:   # (this rank still joins the gather: the others must not wait for it for ever)
+        error = exc
+    hits = _gather_hits(dist, hits, world, stop_row, error)
     if rank != 0:
         return None
     out = args.tsv_path.replace("_filtered.tsv", "_words.tsv")
@@ -618,10 +656,14 @@ def search_main(args, asr_model=None, aligner=None, opener=WavFile, number_to_wo
         if args.logs_path else None
     records = read_tsv(args.tsv_path).to_dict(orient="records")
     mine = sharding.assign_units(_row_costs(records), world)[rank]
-    hits = search_hits(asr_model, aligner, records, mine, wanted, opener, args.offset_time, args.left_offset,
-                       args.right_offset, log, rows_per_launch=max(1, int(getattr(args, "rows_per_launch", 2048))),
-                       batch_lpz=bool(getattr(args, "batch_lpz", False)))
-    hits = _gather_hits(dist, hits, world)
+    hits, error = [], None
+    try:
+        hits = search_hits(asr_model, aligner, records, mine, wanted, opener, args.offset_time, args.left_offset,
+                           args.right_offset, log, rows_per_launch=max(1, int(getattr(args, "rows_per_launch", 2048))),
+                           batch_lpz=bool(getattr(args, "batch_lpz", False)))
+    except Exception as exc:
+        error = exc
+    hits = _gather_hits(dist, hits, world, None, error)
     if rank != 0:
         return None
     out = os.path.join(args.dst_path, args.tsv_path.split("/")[-1].replace(".tsv", "") + "_sos.tsv")

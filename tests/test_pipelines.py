@@ -147,3 +147,40 @@ def test_utterance_stage_failure_costs_one_file_and_resume_redoes_empty_results(
     again = pl.align_utterance_files(ScriptedASR(), ScriptedAligner(mode=sc["mode"], salt=sc["salt"]), df, vad,
                                      str(dst), "", params, opener)
     assert again == []
+
+
+def test_a_sharded_word_run_stops_where_the_reference_stops(pkg):
+    """The reference's single process ends the word-level run at the first unreadable clip
+    (word_level_alignment.py:63-66).  Sharded, every rank reports the row that stopped IT and rank 0 keeps only the
+    hits before the smallest such row -- the table a single process would have written, whatever the world size."""
+    pl = _pipelines(pkg)
+    case = GOLD["words"][0]
+    records = pd.DataFrame(case["rows"]).to_dict(orient="records")
+    n = len(records)
+    assert n >= 6
+    bad = n // 2
+
+    class Picky(ZeroAudio):
+        def __init__(self, seconds, fails):
+            super().__init__(seconds)
+            self._fails = fails
+
+        def load(self, frame_offset, num_frames):
+            if self._fails:
+                raise RuntimeError("unreadable")
+            return super().load(frame_offset, num_frames)
+    for r in records:
+        r["Sample_Path"] = "x/%d.wav" % records.index(r)
+    opener = lambda path: Picky(case["audio_seconds"], path == "x/%d.wav" % bad)
+    mk = lambda: ScriptedAligner(mode=case["mode"], salt=case["salt"])
+    single, stop = pl.word_hits(ScriptedASR(), mk(), records, range(n), opener, return_stop=True, **case["args"])
+    assert stop == bad and all(h[0] < bad for h in single)
+    # two "ranks": even rows / odd rows; the rank that does not own the bad row runs to the end of its share
+    shares = [list(range(0, n, 2)), list(range(1, n, 2))]
+    parts = [pl.word_hits(ScriptedASR(), mk(), records, sh, opener, return_stop=True, **case["args"]) for sh in shares]
+    stops = [s for _, s in parts if s is not None]
+    assert stops == [bad]
+    merged = pl._gather_hits(None, [h for hits, _ in parts for h in hits], 1, min(stops))
+    assert merged == sorted(single)
+    with pytest.raises(RuntimeError):
+        pl._gather_hits(None, [], 1, None, RuntimeError("rank failed"))
