@@ -374,6 +374,10 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
         // backtrack wave holds up every tile to its right (measured: 8 tiles, decision-word mode, +44 % beside
         // the backtrack, 4 tiles +0 %).  In checkpoint mode the backtrack steps back instead (bt_low_prio).
         if (!ckpt && W > 6) cost *= 1.25;
+        // Vocabularies above 64 entries: two labels in three share an LDS bank pair of the (e, m) rows, every gather
+        // is a conflict -- and sixteen waves queueing at one LDS fare worse than eight (r02_vocab.txt: V = 100 as
+        // 14 one-column tiles 454 us, V = 128 as 6 two-column tiles 401 us)
+        if (VP > 64 && K == 1 && W > 8) cost *= 1.3;
         cost += 1e-3 * waves_per_wg;
         if (best_cost < 0.0 || cost < best_cost) {
             best_cost = cost;
@@ -673,7 +677,11 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         // 0.128 / 0.121; the word-level and corpus streams: +-2 %), which stay with decision words.
         const bool pays = use_scratch ? nf * Cmax >= 1024 * 1024
                                       : Cmax >= 544 || Tmax >= 900 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
-        pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
+        // 57..64 entries: a strider's LDS slot is 8 KB; two fill workgroups (a ring of 3 x 17 KB each) then leave a CU
+        // room for ONE backtrack workgroup, the backtrack takes two rounds and the step waits for it (0.281 ms against
+        // 0.269 with decision words; the 15.8 KB backtrack of round 2 made it 0.240) -- decision words there
+        const bool squeezed = pl->VP > 56 && !use_scratch;
+        pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : (pays && !squeezed)) && !std::getenv("CTCFA_DECISION_BITS");
         if (gratis) pl->ckpt = true;   // (vocab <= 64 checked above)
     }
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
