@@ -486,7 +486,11 @@ int ctcfa_max_label_columns(const ctcfa_engine* eng, int32_t vocab) {
     if (!eng || vocab <= 0) return 0;
     const bool gather = vocab > 128;
     const int VP = gather ? 128 : vocab_pitch(vocab);
+#ifdef CTCFA_V32_TWO_PRODUCERS
+    const int nprod = gather ? 1 : 2;
+#else
     const int nprod = (!gather && (VP > 32 || vocab < 32)) ? 2 : 1;
+#endif
     return label_column_limit(eng->lds_limit, VP, nprod, gather);
 }
 
@@ -605,7 +609,11 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->gather = gather;
     // Every vocabulary but the 32-entry one (whose rows a single wave moves with four wide loads per block) takes
     // two producer waves, each staging half the rows of every block: one alone cannot keep six tiles fed.
+#ifdef CTCFA_V32_TWO_PRODUCERS
+    const int nprod = gather ? 1 : 2;
+#else
     const int nprod = (!gather && (pl->VP > 32 || vocab < 32)) ? 2 : 1;
+#endif
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.
@@ -677,11 +685,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         // 0.128 / 0.121; the word-level and corpus streams: +-2 %), which stay with decision words.
         const bool pays = use_scratch ? nf * Cmax >= 1024 * 1024
                                       : Cmax >= 544 || Tmax >= 900 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
-        // 57..64 entries: a strider's LDS slot is 8 KB; two fill workgroups (a ring of 3 x 17 KB each) then leave a CU
-        // room for ONE backtrack workgroup, the backtrack takes two rounds and the step waits for it (0.281 ms against
-        // 0.269 with decision words; the 15.8 KB backtrack of round 2 made it 0.240) -- decision words there
-        const bool squeezed = pl->VP > 56 && !use_scratch;
-        pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : (pays && !squeezed)) && !std::getenv("CTCFA_DECISION_BITS");
+        // (57..64 entries: a strider's LDS slot is 8 KB and only ONE backtrack workgroup fits a CU beside two fill
+        // workgroups -- pipelined 0.281 ms per step against 0.269 with decision words, 0.240 with round 2's 15.8 KB
+        // backtrack; one stream after the other checkpoint mode is 20 % ahead, so it stays)
+        pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
         if (gratis) pl->ckpt = true;   // (vocab <= 64 checked above)
     }
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
