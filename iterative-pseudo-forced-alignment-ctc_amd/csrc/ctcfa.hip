@@ -486,11 +486,7 @@ int ctcfa_max_label_columns(const ctcfa_engine* eng, int32_t vocab) {
     if (!eng || vocab <= 0) return 0;
     const bool gather = vocab > 128;
     const int VP = gather ? 128 : vocab_pitch(vocab);
-#ifdef CTCFA_V32_TWO_PRODUCERS
-    const int nprod = gather ? 1 : 2;
-#else
     const int nprod = (!gather && (VP > 32 || vocab < 32)) ? 2 : 1;
-#endif
     return label_column_limit(eng->lds_limit, VP, nprod, gather);
 }
 
@@ -609,11 +605,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->gather = gather;
     // Every vocabulary but the 32-entry one (whose rows a single wave moves with four wide loads per block) takes
     // two producer waves, each staging half the rows of every block: one alone cannot keep six tiles fed.
-#ifdef CTCFA_V32_TWO_PRODUCERS
-    const int nprod = gather ? 1 : 2;
-#else
     const int nprod = (!gather && (pl->VP > 32 || vocab < 32)) ? 2 : 1;
-#endif
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.

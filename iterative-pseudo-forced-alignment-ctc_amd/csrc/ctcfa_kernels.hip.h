@@ -290,7 +290,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // tiles on its SIMD starve it and the whole workgroup runs at the producer's pace.
         __builtin_amdgcn_s_setprio(CTCFA_PRODUCER_PRIO);
         const int part = my.stage;  // which share of the rows (nprod == 2), and which staged[] counter
-        int fix_mode = 0;           // how two producers split a block: 0 every other row, 2 / 4 every other group of four / eight rows, 3 halves
+        int fix_mode = 0;           // how two producers split a block: 0 every other row, 2 every other group of four rows, 3 halves
         constexpr int PASSES = kRows * VP / 64;
         constexpr int CH = PASSES < 16 ? PASSES : (VP == 32 ? 8 : 16);  // passes per chunk (VP == 32: half a block, one per producer)
         const unsigned char* lpz_bytes = reinterpret_cast<const unsigned char*>(seg_lpz);
@@ -326,7 +326,6 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 // the rows of the block this wave staged: all of them; every other one; every other group of four
                 const int nmine = roles->nprod == 2 ? kRows / 2 : kRows;
                 const int row = roles->nprod != 2 ? lane : fix_mode == 2 ? ((lane >> 2) * 2 + part) * 4 + (lane & 3)
-                                : fix_mode == 4 ? ((lane >> 3) * 2 + part) * 8 + (lane & 7)
                                 : fix_mode == 3 ? part * (kRows / 2) + lane : part + 2 * lane;
                 if (lane < nmine)
                     *reinterpret_cast<float*>(smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) +
@@ -392,11 +391,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // 64 entries: two producers, each takes every other pass (four rows) of a block -- four passes and
             // two register sets per wave, like the single producer of the 32-entry case (one producer with
             // one set had a block's HBM latency in front of every block: 207 us)
-#ifdef CTCFA_V32_TWO_PRODUCERS
-            constexpr int PSTEP = 2;
-#else
-            constexpr int PSTEP = (VP == 64) ? 2 : 1;
-#endif
+            constexpr int PSTEP = (VP == 64) ? 2 : 1;   // (two producers for the 32-entry case too: measured in round 3, 143.8 against 143.1 us)
             constexpr int NP = NPB / PSTEP;
             const int lr = lane / LPR;
             const int lv = (lane % LPR) * 4;
@@ -439,7 +434,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     *reinterpret_cast<float2*>(smem + spc + ((lv == 0) ? p * (RPP * PITCH * 8) : 0)) = sp;
                 }
             };
-            if constexpr (PSTEP == 2) fix_mode = (VP == 64) ? 2 : 4;
+            if constexpr (PSTEP == 2) fix_mode = 2;
             {   // two register sets: loads run a block ahead of the LDS writes
                 // (a third set -- loads two blocks ahead -- measured no faster, and does not fit the
                 // 64-register budget of the narrow tiles)
