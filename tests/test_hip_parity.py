@@ -870,3 +870,50 @@ def test_blank_transition_cost_zero_beyond_64_entries_is_refused(pkg):
     segs = [pkg.synthetic.make_segment(5, 200, 100, 2, 10)]
     with pytest.raises(NotImplementedError):
         _run(pkg, segs, blank_transition_cost_zero=True)
+
+
+def _bursty_segment(seed, T, C, V=32, blank=0):
+    """Emissions with a planted path that alternates runs of a SWITCH in every frame with long stays (and a long
+    wait in the start column): the slope of the path changes abruptly from block to block -- what the speculative
+    windows of the checkpoint-mode backtrack (stride_backtrack_kernel) predict worst."""
+    rng = np.random.default_rng(seed)
+    gt = np.concatenate([[-1], rng.integers(1, V, size=C - 2), [blank]]).astype(np.int64)
+    firsts, t, c = [], int(rng.integers(1, max(2, T // 6))), 1
+    while c < C:
+        run = int(rng.integers(8, 70))                   # columns entered in consecutive frames
+        for _ in range(min(run, C - c)):
+            firsts.append(t)
+            t += 1
+            c += 1
+        t += int(rng.integers(20, 160))                  # ... then a long stay
+    firsts = np.asarray(firsts)
+    firsts = np.minimum(firsts, T - 1 - (C - 1 - np.arange(1, C))[::-1] * 0)   # keep them inside the audio
+    if firsts[-1] >= T:
+        firsts = (firsts.astype(np.float64) * (T - 2) / firsts[-1]).astype(np.int64) + 1
+        firsts = np.maximum.accumulate(np.maximum(firsts, np.arange(1, C)))
+        firsts = np.minimum(firsts, T - 1 - (C - 1 - np.arange(1, C)))
+    col = np.zeros(T, np.int64)
+    col[firsts] += 1
+    col = np.cumsum(col)
+    logits = (2.0 * rng.standard_normal((T, V))).astype(np.float32)
+    sym = np.where(col > 0, gt[np.minimum(np.maximum(col, 1), C - 1)], blank)
+    is_first = np.zeros(T, bool)
+    is_first[firsts] = True
+    logits[np.arange(T), np.where(is_first, sym, np.where(rng.random(T) < 0.3, sym, blank))] += np.float32(9.0)
+    z = logits - logits.max(axis=1, keepdims=True)
+    lpz = (z - np.log(np.exp(z.astype(np.float64)).sum(axis=1, keepdims=True)).astype(np.float32)).astype(np.float32)
+    ub = np.array([1, C - 1], np.int64)
+    return lpz, gt, ub
+
+
+@pytest.mark.parametrize("striders,windows", [(3, 2), (5, 1), (7, 3), (1, 1)])
+def test_checkpoint_backtrack_survives_paths_its_speculation_cannot_predict(pkg, oracle, monkeypatch, striders, windows):
+    """Bursty paths (runs of one SWITCH per frame, then long stays), more striders than shipped (deeper
+    speculation), one / three windows per block: every miss is recomputed from the exact entry column, the results
+    are the oracle's."""
+    monkeypatch.setenv("CTCFA_CHECKPOINT", "1")
+    monkeypatch.setenv("CTCFA_SB_WAVES", str(striders))
+    monkeypatch.setenv("CTCFA_SB_WINDOWS", str(windows))
+    segs = [_bursty_segment(100 + s, T, C) for s, (T, C) in
+            enumerate([(1500, 420), (2400, 700), (900, 300), (3000, 640), (700, 96), (2000, 1100)])]
+    _check(pkg, oracle, segs, _run(pkg, segs))
