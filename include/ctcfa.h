@@ -174,6 +174,11 @@ int ctcfa_plan_get_timings(ctcfa_plan* plan, int n, float* fill_ms, float* backt
  * runs, downloads and synchronises.  This is the call the reference-side binding
  * uses in place of `ctc_segmentation(config, lpz, ground_truth_mat)` +
  * `determine_utterance_segments(...)`.
+ * Vocabularies above 128 entries (sub-word models): where no segment group looks at more than 128
+ * columns (its blank and distinct labels) and the text is long or the flags are not the package's
+ * defaults, the call runs on a compact matrix of exactly those columns (labels renumbered inside,
+ * `state` reported in the caller's ids); otherwise on the wide-vocabulary fill kernel, which is
+ * built for the default flags and up to 961 label columns.  Same for the _resident / _shared entries.
  */
 int ctcfa_align_batch(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int32_t vocab,
                       const int32_t* T, const int32_t* C, const int32_t* U, const float* lpz,

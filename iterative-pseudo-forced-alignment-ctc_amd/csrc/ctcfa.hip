@@ -28,7 +28,7 @@ struct ScratchSlot {
     void* p = nullptr;
     size_t cap = 0;
 };
-enum { kSlotLpz, kSlotIn, kSlotOut, kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kNumSlots };
+enum { kSlotLpz, kSlotIn, kSlotOut, kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kSlotCompact, kNumSlots };
 
 struct ctcfa_engine {
     int device = -1;
@@ -1209,6 +1209,74 @@ hipError_t pinned_get(unsigned char** p, size_t* cap, size_t bytes) {
     return e;
 }
 
+// Wide vocabularies (V > 128) through the staged kernels: per emission block, the columns its segments can look
+// at -- the blank and the distinct labels of the block's texts -- renumbered 0 (blank), 1, 2, ... in ascending
+// order of the original ids.  Possible when no block needs more than 128 of them (a 60 s window of a 5 000-piece
+// model does; an anchor window of 30-60 tokens does not); the caller then runs the whole call on a compact
+// [T, Vc] matrix (ctcfa::compact_kernel) and renumbered labels, and maps `state` back.
+struct VocabRemap {
+    int Vc = 0;                          // columns of the compact matrix
+    std::vector<int32_t> orig;           // [emission blocks][Vc] original column of every compact column
+    std::vector<int32_t> labels;         // renumbered label sequences, laid out like the caller's
+    std::vector<int32_t> block_of;       // [batch] emission block of every segment
+    std::vector<ctcfa::CompactBlock> blocks;
+};
+
+bool build_vocab_remap(int32_t batch, int32_t vocab, int32_t blank, const int32_t* T, const int32_t* C,
+                       const int32_t* emission_of, const int32_t* labels, VocabRemap* out) {
+    std::vector<int32_t> block_index(batch, -1);
+    int nblocks = 0;
+    out->block_of.assign(batch, 0);
+    for (int b = 0; b < batch; ++b) {
+        const int e = emission_of ? emission_of[b] : b;
+        if (e == b) block_index[b] = nblocks++;
+        out->block_of[b] = block_index[e];
+    }
+    std::vector<std::vector<int32_t>> sets(nblocks);
+    int64_t lab_off = 0;
+    for (int b = 0; b < batch; ++b) {
+        std::vector<int32_t>& st = sets[out->block_of[b]];
+        for (int c = 1; c < C[b]; ++c) {
+            const int32_t g = labels[lab_off + c];
+            if (g < 0 || g >= vocab) return false;   // (refused elsewhere; never index with it)
+            if (g != blank) st.push_back(g);
+        }
+        lab_off += C[b];
+    }
+    int vc = 1;
+    for (auto& st : sets) {
+        std::sort(st.begin(), st.end());
+        st.erase(std::unique(st.begin(), st.end()), st.end());
+        vc = std::max(vc, (int)st.size() + 1);
+    }
+    if (vc > 128) return false;
+    vc = std::max(vc, 2);
+    out->Vc = vc;
+    out->orig.assign((size_t)nblocks * vc, blank);
+    for (int k = 0; k < nblocks; ++k)
+        for (size_t i = 0; i < sets[k].size(); ++i) out->orig[(size_t)k * vc + 1 + i] = sets[k][i];
+    out->labels.resize((size_t)lab_off);
+    lab_off = 0;
+    for (int b = 0; b < batch; ++b) {
+        const std::vector<int32_t>& st = sets[out->block_of[b]];
+        out->labels[lab_off] = labels[lab_off];   // the leading -1
+        for (int c = 1; c < C[b]; ++c) {
+            const int32_t g = labels[lab_off + c];
+            out->labels[lab_off + c] = g == blank ? 0 : 1 + (int32_t)(std::lower_bound(st.begin(), st.end(), g) - st.begin());
+        }
+        lab_off += C[b];
+    }
+    out->blocks.resize(nblocks);
+    int64_t src = 0, dst = 0;
+    for (int b = 0; b < batch; ++b)
+        if (block_index[b] >= 0) {
+            out->blocks[block_index[b]] = ctcfa::CompactBlock{src, dst, T[b], 0};
+            src += (int64_t)T[b] * vocab;
+            dst += (int64_t)T[b] * vc;
+        }
+    return true;
+}
+
 // One synchronous alignment call on the engine's stream (or the caller's): transient plan, ONE packed
 // upload of the small inputs, the emissions uploaded (host_lpz) or used where they are (dev_lpz), both
 // kernels, ONE result download.  An anchor iteration issues hundreds of such calls for windows of a
@@ -1230,13 +1298,38 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
         eng->trace_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(t - tp).count();
         tp = t;
     };
+    // vocabularies above 128 entries: the compact matrix of the columns each emission block can look at, if that fits
+    VocabRemap remap;
+    const int32_t wide_vocab = vocab;
+    ctcfa_params compact_params;
+    bool compact = false;
+    // Worth it where the gather kernel cannot serve (its flags: the package's defaults only; 961 label columns) or is
+    // slow (long texts: 1.9 ms against 0.4 for config 3's shape at 128 columns); short anchor windows are as fast
+    // through the gather kernel (tools/wide_vocab_timing.py) and skip the pre-pass.  CTCFA_REMAP=1 forces it.
+    bool remap_wanted = false;
+    if (vocab > 128 && label_width == 1 && params && T && C) {
+        int cmax = 0;
+        for (int b = 0; b < batch; ++b) cmax = std::max(cmax, (int)C[b]);
+        remap_wanted = cmax >= 192 || !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ||
+                       (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) || std::getenv("CTCFA_REMAP");
+    }
+    if (remap_wanted && !std::getenv("CTCFA_NO_REMAP") && !std::getenv("CTCFA_FORCE_GATHER") &&
+        params->blank >= 0 && params->blank < vocab &&
+        build_vocab_remap(batch, vocab, params->blank, T, C, emission_of, labels, &remap)) {
+        compact = true;
+        compact_params = *params;
+        compact_params.blank = 0;
+        params = &compact_params;
+        labels = remap.labels.data();
+        vocab = remap.Vc;
+    }
     ctcfa_plan* pl = nullptr;
     int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of,
                               label_width > 1 ? nullptr : labels, label_width);
     if (rc != CTCFA_OK) return rc;
     lap(0);
     const bool want_seg = U && utt_begin && seg_start && seg_end && seg_score && pl->total_U > 0;
-    const size_t n_lpz = (size_t)pl->total_lpz_T * vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
+    const size_t n_lpz = (size_t)pl->total_lpz_T * wide_vocab, n_lab = (size_t)pl->total_C, n_frm = (size_t)pl->total_T;
     const size_t n_utt = (size_t)pl->total_U, n_ub = n_utt + batch;
     auto cleanup = [&]() {  // the buffers are the engine's scratch; quiesce before the next call reuses them
         (void)hipStreamSynchronize(st);
@@ -1256,7 +1349,9 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     const size_t n_watch = pl->watch.size();
     const size_t in_roles = 0, in_segs = up(sizeof(ctcfa::FillRoles)), in_lab = in_segs + up(sizeof(SegDesc) * (size_t)batch),
                  in_ub = in_lab + up(n_lab * 4 * (size_t)pl->S), in_watch = in_ub + (want_seg ? up(n_ub * 4) : 0),
-                 in_bytes = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc));
+                 in_orig = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc)),
+                 in_cblk = in_orig + (compact ? up(remap.orig.size() * 4) : 0),
+                 in_bytes = in_cblk + (compact ? up(remap.blocks.size() * sizeof(ctcfa::CompactBlock)) : 0);
     const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
                  o_tend = o_state + (state ? up(n_frm * 4) : 0), o_status = o_tend + up((size_t)batch * 4),
                  o_seg = o_status + up((size_t)batch * 4), out_bytes = o_seg + (want_seg ? up(3 * n_utt * 8) : 0);
@@ -1273,9 +1368,25 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     std::memcpy(h + in_lab, labels, n_lab * 4 * (size_t)pl->S);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
     if (n_watch) std::memcpy(h + in_watch, pl->watch.data(), n_watch * sizeof(ctcfa::WatchDesc));
+    if (compact) {
+        std::memcpy(h + in_orig, remap.orig.data(), remap.orig.size() * 4);
+        std::memcpy(h + in_cblk, remap.blocks.data(), remap.blocks.size() * sizeof(ctcfa::CompactBlock));
+    }
     lap(1);
     AB_TRY(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, st));
     if (host_lpz) AB_TRY(hipMemcpyAsync(d_lpz, host_lpz, n_lpz * sizeof(float), hipMemcpyHostToDevice, st));
+    if (compact) {   // the staged kernels run on the compact matrix from here on
+        float* d_compact = nullptr;
+        AB_TRY(scratch_get(eng, kSlotCompact, reinterpret_cast<void**>(&d_compact), (size_t)pl->total_lpz_T * remap.Vc * sizeof(float)));
+        int tmax = 1;
+        for (const auto& cb : remap.blocks) tmax = std::max(tmax, (int)cb.T);
+        const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)tmax * remap.Vc + 4095) / 4096));
+        hipLaunchKernelGGL(ctcfa::compact_kernel, dim3((unsigned)remap.blocks.size(), chunks), dim3(256), 0, st,
+                           reinterpret_cast<const ctcfa::CompactBlock*>(d_in + in_cblk), (const float*)d_lpz,
+                           reinterpret_cast<const int32_t*>(d_in + in_orig), (int)wide_vocab, remap.Vc, d_compact);
+        AB_TRY(hipGetLastError());
+        d_lpz = d_compact;
+    }
     lap(2);
     pl->d_roles = reinterpret_cast<ctcfa::FillRoles*>(d_in + in_roles);
     pl->d_segs = reinterpret_cast<SegDesc*>(d_in + in_segs);
@@ -1300,7 +1411,17 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     lap(5);
     std::memcpy(frame_of_label, ho + o_fol, n_lab * 4);
     std::memcpy(char_prob, ho + o_cp, n_frm * 4);
-    if (state) std::memcpy(state, ho + o_state, n_frm * 4);
+    if (state) {
+        std::memcpy(state, ho + o_state, n_frm * 4);
+        if (compact) {   // label ids of the caller's vocabulary again (-1 / -2: self transition / untouched)
+            int64_t f = 0;
+            for (int b = 0; b < batch; ++b) {
+                const int32_t* cols = remap.orig.data() + (size_t)remap.block_of[b] * remap.Vc;
+                for (int t = 0; t < T[b]; ++t, ++f)
+                    if (state[f] >= 0) state[f] = cols[state[f]];
+            }
+        }
+    }
     std::memcpy(t_end, ho + o_tend, (size_t)batch * 4);
     std::memcpy(status, ho + o_status, (size_t)batch * 4);
     if (want_seg) {

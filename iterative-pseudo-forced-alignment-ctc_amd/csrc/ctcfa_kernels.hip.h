@@ -2148,6 +2148,33 @@ stride_backtrack_kernel(BtArgs a) {
 #undef SB_COUNT
 
 // ---------------------------------------------------------------------------------------
+// Wide vocabularies (sub-word models: hundreds to thousands of entries) through the staged kernels: a segment
+// only ever looks at the emissions of its OWN labels and of the blank.  This pre-pass gathers those columns --
+// at most 128 per emission block -- into a compact matrix [T, Vc] (column 0 = blank, then the block's distinct
+// labels in ascending order, the rest copies of the blank column); labels are renumbered on the host.
+// grid = (emission blocks, row chunks), block = 256 threads.
+// ---------------------------------------------------------------------------------------
+struct CompactBlock {
+    int64_t src_off;   // elements into the wide emissions
+    int64_t dst_off;   // elements into the compact matrix
+    int32_t T;
+    int32_t reserved;
+};
+
+__global__ void __launch_bounds__(256)
+compact_kernel(const CompactBlock* __restrict__ blocks, const float* __restrict__ lpz, const int32_t* __restrict__ orig,
+               int V, int Vc, float* __restrict__ out) {
+    const CompactBlock b = blocks[blockIdx.x];
+    const int32_t* __restrict__ cols = orig + (int64_t)blockIdx.x * Vc;
+    const int64_t n = (int64_t)b.T * Vc;
+    for (int64_t idx = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t t = idx / Vc;
+        const int k = (int)(idx - t * Vc);
+        out[b.dst_off + idx] = lpz[b.src_off + t * V + cols[k]];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Windowed regime (T > min_window_size): ctc-segmentation keeps only W = min(window, T) rows
 // per column; column c's window starts offsets[c] frames into the audio and the step from
 // offsets[c-1] depends on where column c-1 had its (first) maximum.  That makes the fill

@@ -739,10 +739,15 @@ def test_wide_segments_in_a_full_batch(pkg, oracle, engine):
         assert np.array_equal(res[i]["seg_score"], res[i % 3]["seg_score"])
 
 
+@pytest.mark.parametrize("remap", [False, True], ids=["gather-kernel", "compact-remap"])
 @pytest.mark.parametrize("V,blank", [(129, 0), (500, 0), (1000, 37), (4096, 4095)])
-def test_wide_vocabularies_take_the_gather_kernel(pkg, oracle, V, blank):
-    """V > 128 (sub-word CTC models): no LDS staging of vocabulary rows, every lane gathers its
-    own column's emission.  Ragged batch incl. a segment with T < C and one with C = 2."""
+def test_wide_vocabularies(pkg, oracle, monkeypatch, V, blank, remap):
+    """V > 128 (sub-word CTC models).  Default: the columns a segment can look at (its labels and the blank, at
+    most 128 per emission block) are gathered into a compact matrix and the staged kernels run on renumbered
+    labels (`state` comes back in the caller's ids).  CTCFA_NO_REMAP=1, or more than 127 distinct labels: the
+    gather kernel -- no LDS staging of vocabulary rows, every lane gathers its own column's emission.
+    Ragged batch incl. a segment with T < C and one with C = 2."""
+    monkeypatch.setenv("CTCFA_NO_REMAP" if not remap else "CTCFA_REMAP", "1")
     rng = np.random.default_rng(10_000 + V + 1_000_003 * FUZZ_SALT)
     segs = []
     for s in range(12):
@@ -775,8 +780,36 @@ def test_wide_vocabulary_long_label_sequences(pkg, oracle):
     _check(pkg, oracle, segs, _run(pkg, segs))
     kw = dict(min_window_size=200, max_window_size=5000)
     _check(pkg, oracle, segs[1:], _run(pkg, segs[1:], **kw), cfg_kw=kw)
+    # (the first text has 299 distinct labels: too many for the compact matrix, the batch takes the gather kernel,
+    # which is built for the package's default flags only)
     with pytest.raises(NotImplementedError):
         _run(pkg, segs, preamble_transition_cost_zero=False)
+
+
+@pytest.mark.parametrize("V", [300, 2000])
+def test_wide_vocabulary_through_the_compact_matrix_takes_every_flag(pkg, oracle, monkeypatch, V):
+    """Texts of at most 127 distinct labels over a wide vocabulary: the staged kernels on the compact matrix --
+    with the flags the gather kernel refuses (no preamble_transition_cost_zero, blank_transition_cost_zero when the
+    compact vocabulary has at most 64 entries), a blank that is not entry 0, shared emissions, the windowed regime."""
+    monkeypatch.setenv("CTCFA_REMAP", "1")   # (also for the default flags and the short texts of this test)
+    rng = np.random.default_rng(20_000 + V)
+    blank = V - 3
+    segs = []
+    for s in range(8):
+        U = int(rng.integers(1, 5))
+        n = int(rng.integers(3, 12))
+        gt, ub = pkg.synthetic.make_labels(rng, U, n, V, blank=blank)
+        T = int(rng.integers(len(gt), 3 * len(gt) + 80))
+        segs.append((pkg.synthetic.make_emissions(rng, T, V, gt, blank=blank), gt, ub))
+    for kw in (dict(blank=blank), dict(blank=blank, preamble_transition_cost_zero=False),
+               dict(blank=blank, blank_transition_cost_zero=True), dict(blank=blank, min_window_size=64, max_window_size=4000)):
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+    # one window, its text and the text minus its last utterance (shared emissions: one compact matrix, one fill)
+    lpz, gt, ub = segs[3] if len(segs[3][2]) > 2 else segs[0]
+    if len(ub) > 2:
+        config = pkg.CtcSegmentationParameters(index_duration=DUR, blank=blank)
+        res = pkg.ctc_segmentation.get_segments_device(config, [lpz, lpz], [gt, gt[:ub[-2] + 1]], [ub, ub[:-1]])
+        _check(pkg, oracle, [(lpz, gt, ub), (lpz, gt[:ub[-2] + 1], ub[:-1])], res, cfg_kw=dict(blank=blank))
 
 
 def test_serial_call_after_pipelined_calls_waits_for_the_pending_backtrack(pkg, engine):
@@ -867,6 +900,7 @@ def test_blank_transition_cost_zero(pkg, oracle, V):
 
 
 def test_blank_transition_cost_zero_beyond_64_entries_is_refused(pkg):
+    """(65 ... 128 entries: staged as they are, no checkpoint mode there; above 128 the compact matrix decides)"""
     segs = [pkg.synthetic.make_segment(5, 200, 100, 2, 10)]
     with pytest.raises(NotImplementedError):
         _run(pkg, segs, blank_transition_cost_zero=True)
