@@ -61,6 +61,9 @@
 #endif
 #ifndef CTCFA_PF
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
+#ifndef CTCFA_STAMP_BLOCK
+#define CTCFA_STAMP_BLOCK 40  // (CTCFA_STAMP=3: the block, and the one after it, that get a stamp every 8 rows)
+#endif
 #endif
 // Trace words are written once and read by another kernel (another XCD, as likely as not): stored past the L2
 // (nt), they leave no dirty lines for the end-of-kernel write-back to find between two fills.
@@ -758,8 +761,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #pragma unroll
         for (int i = 0; i < kRows; ++i) {
 #if defined(CTCFA_STAMP) && CTCFA_STAMP >= 3   // where inside a block the cycles go: a stamp every 8 rows of block 40
-            if (i % 8 == 0 && j == 40 && lane == 0 && blockIdx.x < 64)
-                (reinterpret_cast<unsigned long long*>(lastcol) + 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[i / 8] = __builtin_amdgcn_s_memtime();
+            if (i % 8 == 0 && (j == CTCFA_STAMP_BLOCK || j == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
+                (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[i / 8] = __builtin_amdgcn_s_memtime();
 #endif
             if (i % kHaloRows == 0 && CTCFA_ABL < 2) {   // group start: the neighbour's columns replace what went wrong in my halo
 #pragma unroll
@@ -864,8 +867,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             }
         }
 #if defined(CTCFA_STAMP) && CTCFA_STAMP >= 3
-        if (j == 40 && lane == 0 && blockIdx.x < 64)
-            (reinterpret_cast<unsigned long long*>(lastcol) + 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[4] = __builtin_amdgcn_s_memtime();
+        if ((j == CTCFA_STAMP_BLOCK || j == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
+            (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[4] = __builtin_amdgcn_s_memtime();
 #endif
         // trace words of this block (fire and forget: this wave never waits on vmcnt); halo lanes hold
         // copies that have gone wrong by now

@@ -24,7 +24,7 @@ d_lpz = torch.from_numpy(lpz.reshape(-1)).to(dev)
 d_lab = torch.from_numpy(gt.astype(np.int32).reshape(-1)).to(dev)
 d_ub = torch.from_numpy(ub.astype(np.int32).reshape(-1)).to(dev)
 d_fol = torch.zeros(B * C, dtype=torch.int32, device=dev)
-d_cp = torch.zeros(B * T, dtype=torch.float32, device=dev)
+d_cp = torch.zeros(B * T + (B * T) % 2 + 3 * 64 * 16 * 8 * 2, dtype=torch.float32, device=dev)   # (room for the stamps of short windows)
 d_seg = torch.zeros(3, B * U, dtype=torch.float64, device=dev)
 d_te = torch.zeros(B, dtype=torch.int32, device=dev)
 d_st = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -40,11 +40,16 @@ for w in range(W):
     print(f"tile {w}: total {np.median(r[:,0]):.0f} cyc  nbr-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  "
           f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  in-rows {np.median(r[:,5]):.0f}  last block {np.median(r[:,6]):.0f}  "
           f"start +{np.median(r[:,7]-raw[:,0,7]):.0f}")
-if B * T * 4 < (64 + nb) * 16 * 8 * 8 or T <= 41 * 32:
-    sys.exit(0)
-raw2 = d_cp.cpu().numpy().view(np.uint64)[64 * 16 * 8: 64 * 16 * 8 + nb * 16 * 8].reshape(nb, 16, 8).astype(np.int64)
-for w in range(W):
-    q = raw2[:, w, :5]
-    print(f"tile {w} block 40: cycles per 8 rows", [int(np.median(q[:, i + 1] - q[:, i])) for i in range(4)])
 r = raw[:, 15, :]
 print(f"producer: total {np.median(r[:,0]):.0f} cyc  space-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  load-wait + write {np.median(r[:,2]):.0f}  blocks {np.median(r[:,4]):.0f}")
+SB = int(os.environ.get("STAMP_BLOCK", "40"))   # (a build with -DCTCFA_STAMP_BLOCK=<n> for short windows)
+if T <= (SB + 2) * 32:
+    sys.exit(0)
+u64 = d_cp.cpu().numpy().view(np.uint64)
+first = u64[64 * 16 * 8: 64 * 16 * 8 + nb * 16 * 8].reshape(nb, 16, 8).astype(np.int64)
+second = u64[2 * 64 * 16 * 8: 2 * 64 * 16 * 8 + nb * 16 * 8].reshape(nb, 16, 8).astype(np.int64)
+for w in range(W):
+    q, q2 = first[:, w, :5], second[:, w, :5]
+    print(f"tile {w} block {SB}: cycles per 8 rows", [int(np.median(q[:, i + 1] - q[:, i])) for i in range(4)],
+          f" to the first row of block {SB + 1}: {int(np.median(q2[:, 0] - q[:, 4]))}",
+          f" block {SB + 1}:", [int(np.median(q2[:, i + 1] - q2[:, i])) for i in range(4)])
