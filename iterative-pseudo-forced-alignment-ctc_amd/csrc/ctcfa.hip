@@ -204,8 +204,11 @@ StrideFn select_strider(int VP) {
 }
 
 // checkpoint-mode backtrack: waves per workgroup (each recomputes and walks one 32-row block at a time)
-int strider_waves() {
-    int n = 3;   // (beside the fill of the next batch more striders cost the fill more than they save: 3 + 1 scorer = 4 waves, one per SIMD)
+// A launch that leaves CUs idle anyway (at most one segment per CU: a window of the anchor iteration, a round of a few
+// files in lockstep) gives every workgroup seven striders -- more hedged windows per turn, nothing beside them to slow
+// down (T = 499: backtrack 15.1 -> 12.8 us, T = 700: 14.6 -> 11.8; profiles/r03_small_window_modes.txt).
+int strider_waves(bool lone) {
+    int n = lone ? 7 : 3;   // (beside the fill of the next batch more striders cost the fill more than they save: 3 + 1 scorer = 4 waves, one per SIMD)
     if (const char* e = std::getenv("CTCFA_SB_WAVES")) n = std::atoi(e);
     return std::max(1, std::min(ctcfa::kSbMaxWaves - 1, n));   // (one more wave may join them as a scorer)
 }
@@ -675,8 +678,15 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         // long segments -- 512 x 3000 frames: 128 label columns 0.106 against 0.139 ms per step, 254: 0.120 / 0.164,
         // 380: 0.142 / 0.207, 640: 0.156 / 0.253 -- and level or a little behind for short windows (4096 x 425 x 54:
         // 0.128 / 0.121; the word-level and corpus streams: +-2 %), which stay with decision words.
-        const bool pays = use_scratch ? nf * Cmax >= 1024 * 1024
-                                      : Cmax >= 544 || Tmax >= 900 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192);
+        // A lone window (at most one segment per CU) is one wave's dependent instruction stream per tile, 6 cycles an
+        // instruction with nothing to hide them behind: 3 instead of 10 per row is worth more than the longer backtrack
+        // from about 200 frames on (T = 499: 17.9 + 12.6 us against 24.3 + 12.7, T = 700: 23.8 + 11.7 against 32.4 + 14.1,
+        // T = 288: 10.4 + 11.6 against 14.2 + 9.0, T = 224: 8.6 + 7.8 against 11.5 + 6.2, T = 160: 6.7 + 9.8 against
+        // 8.9 + 6.6; profiles/r03_small_window_modes.txt).
+        const bool lone = batch <= eng->num_cu;
+        const bool pays = (lone && Tmax >= 208 && !std::getenv("CTCFA_NO_LONE_RULE")) ||
+                          (use_scratch ? nf * Cmax >= 1024 * 1024
+                                       : Cmax >= 544 || Tmax >= 900 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192));
         // (57..64 entries: a strider's LDS slot is 8 KB and only ONE backtrack workgroup fits a CU beside two fill
         // workgroups -- pipelined 0.281 ms per step against 0.269 with decision words, 0.240 with round 2's 15.8 KB
         // backtrack; one stream after the other checkpoint mode is 20 % ahead, so it stays)
@@ -688,7 +698,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     {
         const int Tb = Tmax;
         const int rec = ((Tb + ctcfa::kRows - 1) / ctcfa::kRows * 8 + 15) / 16 * 16;
-        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VP, strider_waves(), Tb) : rec + Tb * 4;
+        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VP, strider_waves(batch <= eng->num_cu), Tb) : rec + Tb * 4;
     }
     ShapeChoice shape{0, 0, 0};
     if (gather) {
@@ -846,10 +856,12 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             for (int b = 0; b < batch; ++b)
                 if (pl->segs[b].prestatus == CTCFA_ST_OK) Cbt = std::max(Cbt, (int)C[b]);
             pl->lab_bytes = (Cbt + 15) / 16 * 16;   // one byte per label
-            pl->bt_waves = strider_waves();
+            pl->bt_waves = strider_waves(batch <= eng->num_cu);
             pl->bt_scorers = (pl->have_utt && !std::getenv("CTCFA_SB_NO_SCORER")) ? 1 : 0;
             pl->fol_bytes = 4 * pl->lab_bytes;
             pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VP, pl->bt_waves, Tbt);
+            while (pl->lds_bt > eng->lds_limit && pl->bt_waves > 1)   // (a very long lone segment: fewer slots rather than no plan)
+                pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VP, --pl->bt_waves, Tbt);
         }
     }
     if (pl->lds_bt > eng->lds_limit) {
@@ -1063,9 +1075,13 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
                               start, windowed ? nullptr : stop, 0, ba);
-    else
-        hipExtLaunchKernelGGL(select_strider(pl->VP), dim3(pl->B), dim3(64 * (pl->bt_waves + pl->bt_scorers)), pl->lds_bt, st,
+    else {
+        // (the LDS is sized for bt_waves; beside the next batch's fill even a lone launch keeps to three striders:
+        // 64 / 128 / 256 segments pipelined 0.1161 / 0.1167 / 0.1178 ms per step with three, 0.1165 / 0.1178 / 0.1190 with seven)
+        const int striders = (beside_fill && !std::getenv("CTCFA_SB_WAVES")) ? std::min(pl->bt_waves, 3) : pl->bt_waves;
+        hipExtLaunchKernelGGL(select_strider(pl->VP), dim3(pl->B), dim3(64 * (striders + pl->bt_scorers)), pl->lds_bt, st,
                               start, windowed ? nullptr : stop, 0, ba);
+    }
     HIP_TRY(pl->eng, hipGetLastError());
     if (windowed) {
         ctcfa::WinParams wp;

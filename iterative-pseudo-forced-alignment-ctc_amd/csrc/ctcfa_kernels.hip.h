@@ -705,6 +705,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #ifdef CTCFA_STAMP   // tuning builds: where a tile's cycles go (tools/stamps2.py reads them from the lastcol workspace)
     unsigned long long st_nbr = 0, st_staged = 0, st_t0 = __builtin_amdgcn_s_memtime();
     int st_nbr_n = 0, st_staged_n = 0;
+    unsigned long long st_first[2] = {0, 0};
 #define CTCFA_STAMP_BEGIN() const unsigned long long st_a = __builtin_amdgcn_s_memtime()
 #define CTCFA_STAMP_END(acc, cnt) do { acc += __builtin_amdgcn_s_memtime() - st_a; ++cnt; } while (0)
 #else
@@ -926,13 +927,17 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         }
         if (w == wstar && wn == 0) block(j, std::integral_constant<int, 1>{});
         else block(j, std::integral_constant<int, 0>{});
+#ifdef CTCFA_STAMP   // when the first two computed blocks ended: what a cold instruction cache costs a launch
+        if (st_first[0] == 0) st_first[0] = __builtin_amdgcn_s_memtime() - st_t0;
+        else if (st_first[1] == 0) st_first[1] = __builtin_amdgcn_s_memtime() - st_t0;
+#endif
     }
     if (lane == 63) flags[w] = kBigCount;   // done (end of the segment or dead zone): nobody waits for this tile again
 #ifdef CTCFA_STAMP
     if (lane == 0 && blockIdx.x < 64) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(lastcol) + (blockIdx.x * 16 + w) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = st_nbr; o[2] = st_staged; o[3] = st_nbr_n; o[4] = st_staged_n;
-        o[5] = jfirst; o[6] = jlast; o[7] = st_t0;
+        o[5] = (st_first[0] << 32) | (st_first[1] & 0xffffffffull); o[6] = jlast; o[7] = st_t0;
     }
     return;
 #endif

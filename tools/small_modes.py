@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Tuning aid: kernel times of one small window (T = 499) under forced trace modes / tile widths."""
+"""Tuning aid: kernel times of one small window (T = 499) under forced trace modes / tile widths.
+   tools/small_modes.py strider : checkpoint mode only, over the strider's wave and window counts (CTCFA_SB_WAVES / _WINDOWS)"""
 import os
 import sys
 import numpy as np
@@ -10,16 +11,23 @@ import __graft_entry__ as ge  # noqa: E402
 pkg = ge.build()
 cfg = pkg.CtcSegmentationParameters(index_duration=320.4769 / 16000)
 cs = pkg.ctc_segmentation
-for T, U, n in ((499, 4, 25), (318, 2, 20), (700, 6, 20)):
+STRIDER = len(sys.argv) > 1 and sys.argv[1] == "strider"
+SHAPES = ((499, 4, 25), (318, 2, 20), (700, 6, 20))
+if len(sys.argv) > 1 and sys.argv[1] == "short":   # where the lone-launch rule should stop
+    SHAPES = ((96, 1, 12), (160, 1, 20), (224, 2, 15), (288, 2, 20), (352, 3, 18))
+for T, U, n in SHAPES:
     seg = pkg.synthetic.make_segment(3, T, 32, U, n)
-    for mode in ("auto", "ckpt", "dec"):
+    for mode in ([f"ckpt waves={w} windows={x}" for w in (2, 3, 5, 7) for x in (1, 2, 3) if x <= w] if STRIDER else ("auto", "ckpt", "dec")):
         os.environ.pop("CTCFA_CHECKPOINT", None)
         os.environ.pop("CTCFA_DECISION_BITS", None)
-        if mode == "ckpt":
+        if mode.startswith("ckpt"):
             os.environ["CTCFA_CHECKPOINT"] = "1"
+        if STRIDER:
+            os.environ["CTCFA_SB_WAVES"] = mode.split("waves=")[1].split()[0]
+            os.environ["CTCFA_SB_WINDOWS"] = mode.split("windows=")[1]
         if mode == "dec":
             os.environ["CTCFA_DECISION_BITS"] = "1"
-        for K in (0, 1, 2):
+        for K in ((0,) if STRIDER or len(sys.argv) > 1 else (0, 1, 2)):
             eng = cs.default_engine()
             try:
                 plan = eng.plan(cfg.to_native(), 32, [T], [len(seg[1])], [len(seg[2]) - 1], force_cols_per_lane=K)

@@ -38,7 +38,7 @@ raw = d_cp.cpu().numpy().view(np.uint64)[: nb * 16 * 8].reshape(nb, 16, 8).astyp
 for w in range(W):
     r = raw[:, w, :]
     print(f"tile {w}: total {np.median(r[:,0]):.0f} cyc  nbr-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  "
-          f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  in-rows {np.median(r[:,5]):.0f}  last block {np.median(r[:,6]):.0f}  "
+          f"staged-wait {np.median(r[:,2]):.0f} ({np.median(r[:,4]):.0f} x)  first two blocks done after {np.median(r[:,5] >> 32):.0f} / {np.median(r[:,5] & 0xffffffff):.0f}  last block {np.median(r[:,6]):.0f}  "
           f"start +{np.median(r[:,7]-raw[:,0,7]):.0f}")
 r = raw[:, 15, :]
 print(f"producer: total {np.median(r[:,0]):.0f} cyc  space-wait {np.median(r[:,1]):.0f} ({np.median(r[:,3]):.0f} x)  load-wait + write {np.median(r[:,2]):.0f}  blocks {np.median(r[:,4]):.0f}")
