@@ -29,7 +29,7 @@ timeout -k 10 600 python tools/sweep_shapes.py 2> $OUT/shapes.err | grep "^|" > 
 && timeout -k 10 300 python tools/windowed_timing.py 2>/dev/null | grep "T=" > $OUT/${R}_windowed.txt \
 && (timeout -k 10 120 ./tools/row_rate) > $OUT/${R}_row_rate.txt 2>&1 \
 && timeout -k 10 200 python tools/call_trace.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_call_trace.txt \
-&& timeout -k 10 200 python tools/small_modes.py 2>/dev/null | grep "T=" > $OUT/${R}_small_window_modes.txt \
+&& (timeout -k 10 200 python tools/small_modes.py 2>/dev/null; timeout -k 10 200 python tools/small_modes.py short 2>/dev/null; timeout -k 10 200 python tools/small_modes.py strider 2>/dev/null) | grep "T=" > $OUT/${R}_small_window_modes.txt \
 && (for n in 3 5; do echo "== striders: $n (+ 1 scoring wave); serial schedule, config 3"; CTCFA_SB_WAVES=$n CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=$PWD/variants/btstamp.so timeout -k 10 100 python tools/bt_stamps.py 2>&1 | grep -v amdgpu.ids || exit 1; done; echo "== backtrack_from_max_t (94 blocks)"; FROM_MAX_T=1 CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=$PWD/variants/btstamp.so timeout -k 10 100 python tools/bt_stamps.py 2>&1 | grep -v amdgpu.ids) > $OUT/${R}_backtrack_cycles.txt \
 && rm -rf gpurun_out/kt && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python3 bench.py --steps 600 --cpu-sample 0 --spinup-steps 200 > /dev/null 2>> $OUT/kstats.err \
 && (f=$(ls gpurun_out/kt/*/*_kernel_trace.csv | head -1); python tools/kernel_gaps.py $f fill_kernel; python tools/kernel_gaps.py $f stride_backtrack) > $OUT/${R}_kernel_gaps.txt && rm -rf gpurun_out/kt \
