@@ -69,7 +69,8 @@ typedef struct ctcfa_params {
     uint32_t flags;                /* CTCFA_FLAG_*; the production scripts use 2 */
     int32_t min_window_size;       /* 8000                                       */
     int32_t max_window_size;       /* 100000                                     */
-    int32_t score_min_mean_over_L; /* scoring_length=30 (iterative_utterance_alignment.py:418) */
+    int32_t score_min_mean_over_L; /* scoring_length=30 (iterative_utterance_alignment.py:418); 1 .. 2^20 frames --
+                                      above 128 the utterances are scored by a second, slower kernel       */
     int32_t reserved;
     double index_duration;         /* samples_to_frames_ratio / fs ("fixed" time stamps) */
 } ctcfa_params;

@@ -53,6 +53,7 @@ struct ctcfa_engine {
 // k - 4, long finished -- the HOST can see that (or wait for it) and no wait has to sit in the GPU queue between
 // two fills (such a packet, satisfied or not, cost config 3 12 us per step).
 constexpr int kWorkspaces = 4;
+constexpr int kMaxScoreLength = 1 << 20;   // score_min_mean_over_L (frames): anything a window can hold
 
 struct ctcfa_plan {
     ctcfa_engine* eng = nullptr;
@@ -567,8 +568,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     const bool gratis = (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) != 0;
     if (gratis && vocab > 64)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero needs a vocabulary of at most 64 entries");
-    if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > 128)
-        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1,128]");
+    if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > kMaxScoreLength)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1, 1048576]");
     // wide vocabularies (sub-word models) take the gather kernel: no LDS staging of vocabulary rows
     const bool gather = vocab > 128 || std::getenv("CTCFA_FORCE_GATHER") != nullptr;
     if (gather && !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO))
@@ -1055,7 +1056,9 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     // batch runs below them instead of above (512 x 1242: 0.362 -> 0.313 ms per step; with six tiles or
     // fewer the backtrack is what a step waits for and keeps its priority)
     if (pl->ckpt && pl->W >= 8) bp.flags |= ctcfa::kBtFlagLowPriority;
-    bp.L = pl->prm.score_min_mean_over_L;
+    // (the backtrack kernels sum at most 128 frames the NumPy way; a longer scoring window is scored again below)
+    const bool rescore = want_seg && pl->prm.score_min_mean_over_L > 128;
+    bp.L = std::min(pl->prm.score_min_mean_over_L, 128);
     bp.rec_bytes = pl->rec_bytes;
     bp.lab_bytes = pl->lab_bytes;
     bp.fol_bytes = pl->fol_bytes;
@@ -1074,13 +1077,13 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
                            want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
-                              start, windowed ? nullptr : stop, 0, ba);
+                              start, (windowed || rescore) ? nullptr : stop, 0, ba);
     else {
         // (the LDS is sized for bt_waves; beside the next batch's fill even a lone launch keeps to three striders:
         // 64 / 128 / 256 segments pipelined 0.1161 / 0.1167 / 0.1178 ms per step with three, 0.1165 / 0.1178 / 0.1190 with seven)
         const int striders = (beside_fill && !std::getenv("CTCFA_SB_WAVES")) ? std::min(pl->bt_waves, 3) : pl->bt_waves;
         hipExtLaunchKernelGGL(select_strider(pl->VP), dim3(pl->B), dim3(64 * (striders + pl->bt_scorers)), pl->lds_bt, st,
-                              start, windowed ? nullptr : stop, 0, ba);
+                              start, (windowed || rescore) ? nullptr : stop, 0, ba);
     }
     HIP_TRY(pl->eng, hipGetLastError());
     if (windowed) {
@@ -1088,18 +1091,25 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.V = pl->V;
         wp.blank = pl->prm.blank;
         wp.flags = pl->prm.flags;
-        wp.L = pl->prm.score_min_mean_over_L;
+        wp.L = std::min(pl->prm.score_min_mean_over_L, 128);
         wp.min_window = pl->prm.min_window_size;
         wp.max_window = pl->prm.max_window_size;
         wp.lds_bytes = pl->lds_win;
         wp.S = pl->S;
         wp.dur = pl->prm.index_duration;
         hipExtLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
-                              pl->lds_win, st, nullptr, stop, 0, (const SegDesc*)pl->d_segs,
+                              pl->lds_win, st, nullptr, rescore ? nullptr : stop, 0, (const SegDesc*)pl->d_segs,
                               (const int32_t*)pl->d_win_list, a.d_lpz, a.d_labels,
                               want_seg ? a.d_utt_begin : (const int32_t*)nullptr, pl->d_win_table, pl->d_win_offs, wp,
                               a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
                               want_seg ? a.d_seg_score : (double*)nullptr, a.d_t_end, a.d_status);
+        HIP_TRY(pl->eng, hipGetLastError());
+    }
+    if (rescore) {
+        hipExtLaunchKernelGGL(ctcfa::rescore_kernel, dim3(pl->B), dim3(ctcfa::kRescoreThreads), 0, st, nullptr, stop, 0,
+                              (const SegDesc*)pl->d_segs, a.d_utt_begin, (const int32_t*)a.d_fol, (const float*)a.d_char_prob,
+                              pl->prm.score_min_mean_over_L, pl->prm.index_duration, a.d_seg_start, a.d_seg_end, a.d_seg_score,
+                              (const int32_t*)a.d_status);
         HIP_TRY(pl->eng, hipGetLastError());
     }
     return CTCFA_OK;

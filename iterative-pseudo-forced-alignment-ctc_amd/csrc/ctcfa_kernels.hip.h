@@ -1145,6 +1145,52 @@ __device__ __forceinline__ double np_pairwise_sum_le128(const float* a, int n) {
     return res;
 }
 
+// NumPy's pairwise summation for any n: above 128 elements the vector is split at n/2 rounded down to a multiple
+// of 8 and the halves are summed on their own (numpy/core/src/umath/loops_utils.h.src, pairwise_sum) -- the
+// recursion as a loop over an explicit stack.  Only the rescoring kernel of score_min_mean_over_L > 128 uses it.
+__device__ inline double np_pairwise_sum_any(const float* a, int n) {
+    constexpr int kDepth = 24;
+    const float* fa[kDepth];
+    int fn[kDepth];
+    int fs[kDepth];
+    double fv[kDepth];
+    int sp = 1;
+    fa[0] = a;
+    fn[0] = n;
+    fs[0] = 0;
+    double ret = 0.0;
+    while (sp > 0) {
+        const int k = sp - 1;
+        if (fs[k] == 0) {
+            if (fn[k] <= 128 || sp >= kDepth) {
+                ret = np_pairwise_sum_le128(fa[k], fn[k]);
+                --sp;
+            } else {
+                int n2 = fn[k] / 2;
+                n2 -= n2 % 8;
+                fs[k] = 1;
+                fa[sp] = fa[k];
+                fn[sp] = n2;
+                fs[sp] = 0;
+                ++sp;
+            }
+        } else if (fs[k] == 1) {
+            int n2 = fn[k] / 2;
+            n2 -= n2 % 8;
+            fv[k] = ret;
+            fs[k] = 2;
+            fa[sp] = fa[k] + n2;
+            fn[sp] = fn[k] - n2;
+            fs[sp] = 0;
+            ++sp;
+        } else {
+            ret = fv[k] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
 // determine_utterance_segments() of ctc-segmentation 1.7.1 for one segment: utterances over
 // waves, lanes = sliding windows.  `fol` = frame of every label column (read with agent-scope
 // loads: written by other waves of this workgroup), `cps` = the segment's char_probs in LDS.
@@ -1152,7 +1198,7 @@ struct NoTick {
     __device__ __forceinline__ void operator()() const {}
 };
 
-template <int NTHREADS, class Tick = NoTick>
+template <int NTHREADS, class Tick = NoTick, bool ANY_L = false>
 __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, double dur, const int32_t* ub,
                                                  const int32_t* fol, const float* cps, int T, int C, int U,
                                                  double* __restrict__ seg_start, double* __restrict__ seg_end,
@@ -1184,7 +1230,7 @@ __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, doubl
             long long lo = start_t < 0 ? 0 : start_t, hi = end_t > T ? T : end_t;
             if (lo > T) lo = T;
             if (hi < lo) hi = lo;
-            min_avg = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
+            min_avg = (ANY_L ? np_pairwise_sum_any(cps + lo, (int)(hi - lo)) : np_pairwise_sum_le128(cps + lo, (int)(hi - lo))) / (double)(hi - lo);
         } else {
             double local = 0.0;
             int it = 0;
@@ -1193,7 +1239,7 @@ __device__ __forceinline__ void score_utterances(const SegDesc& sd, int L, doubl
                 long long lo = t0 < 0 ? 0 : t0, hi = (t0 + n > T) ? T : t0 + n;
                 if (lo > T) lo = T;
                 if (hi < lo) hi = lo;
-                const double m = np_pairwise_sum_le128(cps + lo, (int)(hi - lo)) / (double)(hi - lo);
+                const double m = (ANY_L ? np_pairwise_sum_any(cps + lo, (int)(hi - lo)) : np_pairwise_sum_le128(cps + lo, (int)(hi - lo))) / (double)(hi - lo);
                 if (m < local) local = m;
             }
 #pragma unroll
@@ -2154,6 +2200,23 @@ stride_backtrack_kernel(BtArgs a) {
 #undef SB_LAP
 #undef SB_MARK
 #undef SB_COUNT
+
+// ---------------------------------------------------------------------------------------
+// score_min_mean_over_L above 128 frames (2.6 s; the reference passes 30): the backtrack kernels keep their fixed
+// 128-element summation and are given L = 128; this kernel then scores the utterances of every aligned segment
+// again with the caller's L, from frame_of_label and char_prob where the backtrack left them in HBM.  Rare option:
+// written to be right (NumPy's summation order at any length), not fast.  grid = segments, block = 256.
+// ---------------------------------------------------------------------------------------
+constexpr int kRescoreThreads = 256;
+__global__ void __launch_bounds__(kRescoreThreads)
+rescore_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ utt_begin, const int32_t* __restrict__ frame_of_label,
+               const float* __restrict__ char_prob, int L, double dur, double* __restrict__ seg_start, double* __restrict__ seg_end,
+               double* __restrict__ seg_score, const int32_t* __restrict__ status_out) {
+    const SegDesc sd = segs[blockIdx.x];
+    if (sd.U <= 0 || status_out[sd.seg_index] != 0) return;   // (failed segments keep their zeros)
+    score_utterances<kRescoreThreads, NoTick, true>(sd, L, dur, utt_begin + sd.utt_off + sd.seg_index, frame_of_label + sd.lab_off,
+                                                    char_prob + sd.frm_off, sd.T, sd.C, sd.U, seg_start, seg_end, seg_score);
+}
 
 // ---------------------------------------------------------------------------------------
 // Wide vocabularies (sub-word models: hundreds to thousands of entries) through the staged kernels: a segment

@@ -253,6 +253,19 @@ def test_scoring_lengths(pkg, oracle):
         _check(pkg, oracle, segs, _run(pkg, segs, score_min_mean_over_L=L), dict(score_min_mean_over_L=L))
 
 
+def test_scoring_lengths_above_128_frames(pkg, oracle):
+    """score_min_mean_over_L beyond the 128 frames the backtrack kernels sum in one go (rescore_kernel: NumPy's
+    pairwise summation at any length) -- utterances longer than L (sliding means) and shorter (one mean over the
+    whole span), a failed segment in the batch, and a segment of the windowed regime."""
+    syn = pkg.synthetic
+    segs = [syn.make_segment(640 + s, T, 32, U, n) for s, (T, U, n) in
+            enumerate([(3000, 2, 40), (2200, 5, 20), (1400, 1, 60), (900, 3, 10), (40, 4, 25)])]
+    for L in (129, 136, 200, 257, 500, 1023, 3000):
+        _check(pkg, oracle, segs, _run(pkg, segs, score_min_mean_over_L=L), dict(score_min_mean_over_L=L))
+    kw = dict(min_window_size=1000, max_window_size=8000, score_min_mean_over_L=300)
+    _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+
+
 def test_longer_segments_full_size_column_count(pkg, oracle):
     """T = 3000, C = 640 (BASELINE.json configs[2] geometry), a handful of segments."""
     syn = pkg.synthetic
