@@ -59,7 +59,7 @@ extern "C" {
                                               counter (bounded spins: a bug must not hang the GPU) */
 
 /* flags (CtcSegmentationParameters.flags + the backtrack switch) */
-#define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; vocab <= 64 (forces checkpoint mode) */
+#define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; forces checkpoint mode: vocab <= 64, or (ctcfa_align_batch*) <= 63 distinct labels per segment */
 #define CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO 2u /* default of the package         */
 #define CTCFA_FLAG_BACKTRACK_FROM_MAX_T 4u
 

@@ -567,7 +567,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // the two apart (the decision words of the other mode are computed with the fill's step)
     const bool gratis = (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) != 0;
     if (gratis && vocab > 64)
-        return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero needs a vocabulary of at most 64 entries");
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED,
+                       "blank_transition_cost_zero needs a vocabulary of at most 64 entries (the host-buffer and resident entries "
+                       "also take larger ones whose launch looks at no more than 63 distinct labels)");
     if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > kMaxScoreLength)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1, 1048576]");
     // wide vocabularies (sub-word models) take the gather kernel: no LDS staging of vocabulary rows
@@ -1249,7 +1251,7 @@ struct VocabRemap {
 };
 
 bool build_vocab_remap(int32_t batch, int32_t vocab, int32_t blank, const int32_t* T, const int32_t* C,
-                       const int32_t* emission_of, const int32_t* labels, VocabRemap* out) {
+                       const int32_t* emission_of, const int32_t* labels, int max_cols, VocabRemap* out) {
     std::vector<int32_t> block_index(batch, -1);
     int nblocks = 0;
     out->block_of.assign(batch, 0);
@@ -1275,7 +1277,7 @@ bool build_vocab_remap(int32_t batch, int32_t vocab, int32_t blank, const int32_
         st.erase(std::unique(st.begin(), st.end()), st.end());
         vc = std::max(vc, (int)st.size() + 1);
     }
-    if (vc > 128) return false;
+    if (vc > max_cols) return false;
     vc = std::max(vc, 2);
     out->Vc = vc;
     out->orig.assign((size_t)nblocks * vc, blank);
@@ -1333,15 +1335,18 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     // slow (long texts: 1.9 ms against 0.4 for config 3's shape at 128 columns); short anchor windows are as fast
     // through the gather kernel (tools/wide_vocab_timing.py) and skip the pre-pass.  CTCFA_REMAP=1 forces it.
     bool remap_wanted = false;
+    const bool gratis_call = params && (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO);
     if (vocab > 128 && label_width == 1 && params && T && C) {
         int cmax = 0;
         for (int b = 0; b < batch; ++b) cmax = std::max(cmax, (int)C[b]);
-        remap_wanted = cmax >= 192 || !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ||
-                       (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) || std::getenv("CTCFA_REMAP");
+        remap_wanted = cmax >= 192 || !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) || gratis_call ||
+                       std::getenv("CTCFA_REMAP");
+    } else if (vocab > 64 && gratis_call && label_width == 1 && T && C) {
+        remap_wanted = true;   // (checkpoint mode, the only one that takes the flag, stages at most 64 columns)
     }
     if (remap_wanted && !std::getenv("CTCFA_NO_REMAP") && !std::getenv("CTCFA_FORCE_GATHER") &&
         params->blank >= 0 && params->blank < vocab &&
-        build_vocab_remap(batch, vocab, params->blank, T, C, emission_of, labels, &remap)) {
+        build_vocab_remap(batch, vocab, params->blank, T, C, emission_of, labels, gratis_call ? 64 : 128, &remap)) {
         compact = true;
         compact_params = *params;
         compact_params.blank = 0;

@@ -799,6 +799,21 @@ def test_wide_vocabulary_long_label_sequences(pkg, oracle):
         _run(pkg, segs, preamble_transition_cost_zero=False)
 
 
+def test_blank_transition_cost_zero_between_65_and_128_entries(pkg, oracle):
+    """gratis_blank exists in checkpoint mode only, which stages at most 64 vocabulary columns: a vocabulary of
+    65..128 entries takes it through the compact matrix when the launch looks at no more than 63 distinct labels."""
+    for V in (65, 100, 128):
+        rng = np.random.default_rng(21_000 + V)
+        blank = int(rng.integers(0, V))
+        segs = []
+        for s in range(6):
+            gt, ub = pkg.synthetic.make_labels(rng, int(rng.integers(1, 4)), int(rng.integers(3, 10)), V, blank=blank)
+            T = int(rng.integers(len(gt), 3 * len(gt) + 60))
+            segs.append((pkg.synthetic.make_emissions(rng, T, V, gt, blank=blank), gt, ub))
+        kw = dict(blank=blank, blank_transition_cost_zero=True)
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+
+
 @pytest.mark.parametrize("V", [300, 2000])
 def test_wide_vocabulary_through_the_compact_matrix_takes_every_flag(pkg, oracle, monkeypatch, V):
     """Texts of at most 127 distinct labels over a wide vocabulary: the staged kernels on the compact matrix --
@@ -912,11 +927,15 @@ def test_blank_transition_cost_zero(pkg, oracle, V):
     _check(pkg, oracle, members, _run(pkg, members, **kw), cfg_kw=kw)
 
 
-def test_blank_transition_cost_zero_beyond_64_entries_is_refused(pkg):
-    """(65 ... 128 entries: staged as they are, no checkpoint mode there; above 128 the compact matrix decides)"""
-    segs = [pkg.synthetic.make_segment(5, 200, 100, 2, 10)]
+@pytest.mark.parametrize("V", [100, 400])
+def test_blank_transition_cost_zero_over_more_than_63_distinct_labels_is_refused(pkg, V):
+    """(checkpoint mode -- the only one that takes the flag -- stages at most 64 vocabulary columns: a launch that looks
+    at more distinct labels than that is refused, whatever the size of the vocabulary)"""
+    rng = np.random.default_rng(3)
+    gt = np.r_[-1, np.arange(1, 80)].astype(np.int64)
+    lpz = pkg.synthetic.make_emissions(rng, 300, V, gt, blank=0)
     with pytest.raises(NotImplementedError):
-        _run(pkg, segs, blank_transition_cost_zero=True)
+        _run(pkg, [(lpz, gt, np.array([1, len(gt) - 1]))], blank_transition_cost_zero=True)
 
 
 def _bursty_segment(seed, T, C, V=32, blank=0):
