@@ -65,6 +65,39 @@ def test_ragged_batch_matches_oracle(pkg, oracle):
     _check(pkg, oracle, segs, _run(pkg, segs))
 
 
+def test_emissions_with_minus_infinity(pkg, oracle):
+    """log(0) in the emissions (a masked vocabulary entry, an underflown posterior): sums stay at -inf or are lifted to
+    max_prob by the recurrence's third operand, residuals become infinite -- the same IEEE arithmetic on both sides."""
+    syn = pkg.synthetic
+    segs = []
+    for s, (T, U, n) in enumerate([(300, 3, 14), (700, 6, 20), (120, 1, 30), (1500, 10, 26)]):
+        lpz, gt, ub = syn.make_segment(900 + s, T, 32, U, n)
+        rng = np.random.default_rng(950 + s)
+        lpz = lpz.copy()
+        lpz[rng.random(lpz.shape) < 0.04] = -np.inf           # scattered entries
+        lpz[:, int(rng.integers(1, 32))] = -np.inf             # one vocabulary entry masked everywhere
+        lpz[int(rng.integers(1, T))] = -np.inf                 # one frame with nothing at all
+        segs.append((lpz, gt, ub))
+    _check(pkg, oracle, segs, _run(pkg, segs))
+
+
+def test_emissions_that_are_not_log_posteriors_do_not_hang(pkg):
+    """NaNs, +inf and positive numbers: whatever comes out (the package would not say anything sensible either), every
+    segment answers with a status, and the engine serves the next call."""
+    syn = pkg.synthetic
+    bad = []
+    for s, fill in enumerate([np.nan, np.inf, 50.0]):
+        lpz, gt, ub = syn.make_segment(970 + s, 600, 32, 5, 20)
+        lpz = lpz.copy()
+        rng = np.random.default_rng(980 + s)
+        lpz[rng.random(lpz.shape) < 0.1] = fill
+        bad.append((lpz, gt, ub))
+    res = _run(pkg, bad)
+    assert len(res) == 3 and all(isinstance(int(r["status"]), int) for r in res)
+    good = [syn.make_segment(990, 400, 32, 4, 20)]
+    assert _run(pkg, good)[0]["status"] == 0
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 8, 10, 12, 16])
 def test_every_lane_tile_width(pkg, oracle, engine, K):
     """Force each compiled cols-per-lane variant through the plan API (device buffers)."""
