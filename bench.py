@@ -388,8 +388,24 @@ def spawn_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CTCFA_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], cwd=ROOT, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
+    # (a rank that dies before the first barrier would leave the others waiting in the rendezvous for ever: the
+    # launcher watches its own children and ends the rest -- exactly these processes -- when one fails)
+    import time
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    out0 = procs[0].stdout.read().decode()
     if cpu_file:
         os.unlink(cpu_file)
     sys.stdout.write(out0)
