@@ -408,7 +408,9 @@ def spawn_ranks(args):
     out0 = procs[0].stdout.read().decode()
     if cpu_file:
         os.unlink(cpu_file)
-    sys.stdout.write(out0)
+    # (ONE JSON line on stdout: what libraries of rank 0 may have printed there -- gloo announces its peers -- goes to stderr)
+    for line in out0.splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     bad = [rc for rc in rcs if rc != 0]
     raise SystemExit(bad[0] if bad else 0)
