@@ -185,6 +185,12 @@ FillFn select_fill(int K, int VP, bool ck) {
         case 96: return fill_any<96>(K, ck);
         case 112: return fill_any<112>(K, ck);
         case 128: return fill_any<128>(K, ck);
+        case 160: return fill_any<160>(K, ck);
+        case 192: return fill_any<192>(K, ck);
+        case 256: return fill_any<256>(K, ck);
+#elif defined(CTCFA_DEV_WIDE)   // (tuning builds of the wide pitches)
+        case 128: return fill_any<128>(K, ck);
+        case 256: return fill_any<256>(K, ck);
 #endif
         default: return nullptr;
     }
@@ -278,7 +284,9 @@ bool shape_launchable(int K, int W, int nprod) {
 int lds_bytes_fill(int NS, int W, int K, int VP, int nwatch = 0) {
     // emission ring (NS slots) + exchange rings + last-column ring + counters + sink
     // (+ shared fills: a ring and a target offset per watch column)
-    return NS * ctcfa::kRows * (VP + ctcfa::kPitchPad) * 8 + W * ctcfa::kExchangeRing * ctcfa::halo_lanes(K) * K * 4 +
+    // (above 80 entries the ring holds e alone: VP + 4 floats a row)
+    const int row_bytes = VP > 80 ? (VP + 4) * 4 : (VP + ctcfa::kPitchPad) * 8;
+    return NS * ctcfa::kRows * row_bytes + W * ctcfa::kExchangeRing * ctcfa::halo_lanes(K) * K * 4 +
            64 * 4 + ctcfa::kFlagInts * 4 + ctcfa::kSinkBytes + nwatch * (64 * 4 + 8);
 }
 
@@ -286,8 +294,9 @@ int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
 int vocab_pitch(int vocab) {
     return vocab <= 32 ? 32 : vocab <= 40 ? 40 : vocab <= 48 ? 48 : vocab <= 56 ? 56 : vocab <= 64 ? 64
-           : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : 128;
+           : vocab <= 80 ? 80 : vocab <= 96 ? 96 : vocab <= 112 ? 112 : vocab <= 128 ? 128 : vocab <= 160 ? 160 : vocab <= 192 ? 192 : 256;
 }
+constexpr int kMaxStagedVocab = 256;   // wider vocabularies: the compact matrix of a call's own labels, or the gather kernel
 
 // Label columns the widest launch shape of the fill kernel covers (more: status CTCFA_ST_TEXT_TOO_LONG for that
 // segment).  The same rules as pick_shape: tile widths and wave counts of the launch bounds, a ring of 4 slots
@@ -488,7 +497,7 @@ const char* ctcfa_last_error(const ctcfa_engine* eng) { return eng ? eng->err.c_
 
 int ctcfa_max_label_columns(const ctcfa_engine* eng, int32_t vocab) {
     if (!eng || vocab <= 0) return 0;
-    const bool gather = vocab > 128;
+    const bool gather = vocab > kMaxStagedVocab;
     const int VP = gather ? 128 : vocab_pitch(vocab);
     const int nprod = (!gather && (VP > 32 || vocab < 32)) ? 2 : 1;
     return label_column_limit(eng->lds_limit, VP, nprod, gather);
@@ -573,10 +582,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > kMaxScoreLength)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1, 1048576]");
     // wide vocabularies (sub-word models) take the gather kernel: no LDS staging of vocabulary rows
-    const bool gather = vocab > 128 || std::getenv("CTCFA_FORCE_GATHER") != nullptr;
+    const bool gather = vocab > kMaxStagedVocab || std::getenv("CTCFA_FORCE_GATHER") != nullptr;
     if (gather && !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO))
         return set_err(eng, CTCFA_ERR_UNSUPPORTED,
-                       "vocab > 128 needs preamble_transition_cost_zero (the package default)");
+                       "vocab > 256 needs preamble_transition_cost_zero (the package default)");
     if (gratis && gather)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "blank_transition_cost_zero is not built for the wide-vocabulary fill kernel");
     GUARD_DEVICE(eng);
@@ -957,7 +966,7 @@ int ctcfa_plan_get_info(const ctcfa_plan* pl, ctcfa_plan_info* info) {
     info->batch = pl->B;
     info->cols_per_lane = pl->K;
     info->waves_per_seg = pl->roles.nstages;
-    info->vocab_pitch = pl->VP + ctcfa::kPitchPad;
+    info->vocab_pitch = pl->VP > 80 ? pl->VP + 4 : pl->VP + ctcfa::kPitchPad;   // entries per ring row (4 B each above 80 entries, else 8 B)
     info->lds_bytes = pl->lds_fill;
     info->n_blocks_max = pl->nblk_max;
     info->workspace_bytes = pl->bits_words * 4 + pl->total_T * 4;
@@ -1237,10 +1246,10 @@ hipError_t pinned_get(unsigned char** p, size_t* cap, size_t bytes) {
     return e;
 }
 
-// Wide vocabularies (V > 128) through the staged kernels: per emission block, the columns its segments can look
+// Wide vocabularies (V > 256) through the staged kernels: per emission block, the columns its segments can look
 // at -- the blank and the distinct labels of the block's texts -- renumbered 0 (blank), 1, 2, ... in ascending
-// order of the original ids.  Possible when no block needs more than 128 of them (a 60 s window of a 5 000-piece
-// model does; an anchor window of 30-60 tokens does not); the caller then runs the whole call on a compact
+// order of the original ids.  Possible when no block needs more than 256 of them (a 60 s window of a 5 000-piece
+// model may; an anchor window of 30-60 tokens does not); the caller then runs the whole call on a compact
 // [T, Vc] matrix (ctcfa::compact_kernel) and renumbered labels, and maps `state` back.
 struct VocabRemap {
     int Vc = 0;                          // columns of the compact matrix
@@ -1336,7 +1345,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     // through the gather kernel (tools/wide_vocab_timing.py) and skip the pre-pass.  CTCFA_REMAP=1 forces it.
     bool remap_wanted = false;
     const bool gratis_call = params && (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO);
-    if (vocab > 128 && label_width == 1 && params && T && C) {
+    if (vocab > kMaxStagedVocab && label_width == 1 && params && T && C) {
         int cmax = 0;
         for (int b = 0; b < batch; ++b) cmax = std::max(cmax, (int)C[b]);
         remap_wanted = cmax >= 192 || !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) || gratis_call ||
@@ -1346,7 +1355,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     }
     if (remap_wanted && !std::getenv("CTCFA_NO_REMAP") && !std::getenv("CTCFA_FORCE_GATHER") &&
         params->blank >= 0 && params->blank < vocab &&
-        build_vocab_remap(batch, vocab, params->blank, T, C, emission_of, labels, gratis_call ? 64 : 128, &remap)) {
+        build_vocab_remap(batch, vocab, params->blank, T, C, emission_of, labels, gratis_call ? 64 : kMaxStagedVocab, &remap)) {
         compact = true;
         compact_params = *params;
         compact_params.blank = 0;

@@ -231,8 +231,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const bool preamble = (cost_flags & 1) != 0;
     const bool gratis = (cost_flags & 2) != 0;
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int PITCH = VP + kPitchPad;  // row pitch in (e, m) entries; entry VP = start-column pseudo label
-    constexpr int SLOT_BYTES = kRows * PITCH * 8;
+    constexpr bool E1 = VP > 80;           // the ring holds e alone (4 B an entry), the tiles work out m: see the producers
+    static_assert(!(VP > 64 && CK), "checkpoint mode exists for vocabularies of at most 64 entries");
+    constexpr int PITCH = E1 ? VP + 4 : VP + kPitchPad;  // row pitch in entries; entry VP = start-column pseudo label
+    constexpr int ROW_BYTES = PITCH * (E1 ? 4 : 8);
+    constexpr int SLOT_BYTES = kRows * ROW_BYTES;
     constexpr int HL = halo_lanes(K);      // halo lanes of a tile
     constexpr int XW = HL * K;             // floats per exchange row
 
@@ -325,7 +328,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // blank_transition_cost_zero: the blank entry's stay step of the rows this wave just staged becomes 0
             // (one store per block, after the rows' own stores -- LDS executes a wave's operations in order; nothing
             // in the per-row code, so nothing in the way when the flag is off)
-            if (gratis) {
+            if (!E1 && gratis) {   // (the plan refuses the flag above 64 entries)
                 // the rows of the block this wave staged: all of them; every other one; every other group of four
                 const int nmine = roles->nprod == 2 ? kRows / 2 : kRows;
                 const int row = roles->nprod != 2 ? lane : fix_mode == 2 ? ((lane >> 2) * 2 + part) * 4 + (lane & 3)
@@ -546,8 +549,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 write_chunk(jb + 1, p0, eb);
                 publish(jb + 1);
             }
-        } else if constexpr (VP > 64) {
-            // ---- character vocabularies between 65 and 128 entries (e.g. 76 for French): a row per
+        } else if constexpr (VP > 64 && !E1) {
+            // ---- character vocabularies between 65 and 80 entries (e.g. 76 for French), (e, m) pairs as below 64: a row per
             // pass, lane i holds entries i and 64 + i; lane 0 also writes the start-column pseudo entry.
             // Two producers, each stages every other row.  Under preamble_transition_cost_zero the start-column entry
             // is written once for the whole ring; rows past the end of the segment repeat its last row (nothing
@@ -602,6 +605,81 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     *reinterpret_cast<float2*>(smem + static_cast<uint32_t>((idx / kRows) * SLOT_BYTES + (idx % kRows) * (PITCH * 8) + VP * 8)) =
                         make_float2(-__builtin_inff(), 0.0f);
             runw(std::integral_constant<int, 2>{});   // (the plan always gives these vocabularies two producers)
+        } else if constexpr (E1) {
+            // ---- vocabularies of 81 .. 256 entries (character sets like French's 76, small sub-word models): the ring
+            // holds the emissions alone, one float per entry (e only: a row of (e, m) pairs is 2 x 8 B x VP -- random
+            // labels then meet in the same LDS banks three or four deep, and one workgroup takes most of a CU's LDS);
+            // the tiles work m = max(blank, e, -1e9) out themselves from the row's blank posterior, which lane 0 leaves
+            // in entries VP + 2 (for label columns) and VP + 3 (for the start column and the padding left of it: 0 under
+            // preamble_transition_cost_zero).  A row per pass, lane i holds entries i, 64 + i, ...; two producers, each
+            // stages every other row.  The start-column pseudo entry (e = -inf) is written once for the whole ring; rows
+            // past the end of the segment repeat its last row (nothing reads what follows).
+            constexpr int NE = (VP + 63) / 64;
+            int sv[NE];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) sv[q] = lane + 64 * q < V ? lane + 64 * q : V - 1;
+            auto runw = [&](auto parts_tag) {
+                constexpr int PARTS = decltype(parts_tag)::value;
+                constexpr int NR = kRows / PARTS;             // rows of a block this wave stages: part, part + PARTS, ...
+                // Two register sets: the loads of a chunk are issued a whole chunk before they are written (with one set
+                // every block had an HBM round trip in front of it: 3.3 us a block, 310 us for config 3's shape whatever
+                // the vocabulary).  A chunk is this wave's 16 rows of a block, or 8 of them where a lane holds three or
+                // four entries (two sets of 16 would be 96 / 128 registers).
+                constexpr int CR = NE <= 2 ? NR : NR / 2;     // rows per chunk
+                constexpr int CPB = NR / CR;                  // chunks per block
+                auto cload = [&](int ch, float (&e)[NE][CR]) {
+                    const int t0 = (ch / CPB) * kRows + 1 + part + (ch % CPB) * (CR * PARTS);
+#pragma unroll
+                    for (int r = 0; r < CR; ++r) {
+                        int t = t0 + r * PARTS;
+                        t = t < T ? t : T - 1;
+                        const unsigned char* rowp = lpz_bytes + static_cast<uint32_t>(t * V) * 4u;
+#pragma unroll
+                        for (int q = 0; q < NE; ++q) e[q][r] = *reinterpret_cast<const float*>(rowp + static_cast<uint32_t>(sv[q]) * 4u);
+                    }
+                };
+                auto cwrite = [&](int ch, const float (&e)[NE][CR]) {
+                    unsigned char* slot = smem + static_cast<uint32_t>(((ch / CPB) % NS) * SLOT_BYTES) +
+                                          static_cast<uint32_t>((part + (ch % CPB) * (CR * PARTS)) * ROW_BYTES);
+                    // lanes past the vocabulary park their stores on the pad entry VP + 1
+                    unsigned char* d[NE];
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) d[q] = slot + static_cast<uint32_t>((lane + 64 * q < V ? lane + 64 * q : VP + 1) * 4);
+                    unsigned char* dx = slot + static_cast<uint32_t>((VP + 2) * 4);
+#pragma unroll
+                    for (int r = 0; r < CR; ++r) {
+                        float src = e[0][r];   // the register that holds the blank entry (wave-uniform choice)
+#pragma unroll
+                        for (int q = 1; q < NE; ++q) src = (blank >> 6) == q ? e[q][r] : src;
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), blank & 63));
+#pragma unroll
+                        for (int q = 0; q < NE; ++q) {
+                            notneg |= !(e[q][r] <= 0.0f);
+                            *reinterpret_cast<float*>(d[q] + r * (PARTS * ROW_BYTES)) = e[q][r];
+                        }
+                        if (lane == 0) *reinterpret_cast<float2*>(dx + r * (PARTS * ROW_BYTES)) = make_float2(lb, preamble ? 0.0f : lb);
+                    }
+                };
+                const int nch = nblk * CPB;
+                float ea[NE][CR], eb[NE][CR];
+                cload(0, ea);
+                for (int ch = 0; ch < nch; ch += 2) {
+                    if (ch + 1 < nch) cload(ch + 1, eb);
+                    if (ch % CPB == 0) wait_space(ch / CPB);
+                    cwrite(ch, ea);
+                    if (ch % CPB == CPB - 1) publish(ch / CPB);
+                    if (ch + 1 >= nch) break;
+                    if (ch + 2 < nch) cload(ch + 2, ea);
+                    if ((ch + 1) % CPB == 0) wait_space((ch + 1) / CPB);
+                    cwrite(ch + 1, eb);
+                    if ((ch + 1) % CPB == CPB - 1) publish((ch + 1) / CPB);
+                }
+            };
+            if (part == 0)   // start-column entry of every row of the ring, once (before the first publish of this wave: LDS order)
+                for (int idx = lane; idx < NS * kRows; idx += 64)
+                    *reinterpret_cast<float*>(smem + static_cast<uint32_t>((idx / kRows) * SLOT_BYTES + (idx % kRows) * ROW_BYTES + VP * 4)) =
+                        -__builtin_inff();
+            runw(std::integral_constant<int, 2>{});   // (the plan always gives these vocabularies two producers)
         }
         return;
     }
@@ -611,7 +689,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     float prev[K];
     float hx[K];        // halo values to put in at the start of the next group
     uint32_t dec[K];
-    uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair in row 0 of the current slot
+    uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair (E1: of its e) in row 0 of the current slot
+    bool startlike[K];  // E1: the start column or padding left of it (its m comes from entry VP + 3 of the row)
+    uint32_t xaddr = static_cast<uint32_t>((VP + 2) * 4);   // E1: the row's (blank, start-column stay step) pair, same bookkeeping as gaddr
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int pc = cbase + lane * K + k;
@@ -620,7 +700,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         if (c <= 0) lab = VP;                  // start column / left padding
         else if (c < C) lab = seg_lab[c];
         else lab = blank;                      // right padding: any valid entry
-        gaddr[k] = static_cast<uint32_t>(lab) * 8u;
+        gaddr[k] = static_cast<uint32_t>(lab) * (E1 ? 4u : 8u);
+        startlike[k] = c <= 0;
         prev[k] = (c <= 0) ? 0.0f : kProbMax;  // table[0,0] = 0, table[0,c>0] = -1e9
         hx[k] = prev[k];
         dec[k] = 0u;
@@ -728,13 +809,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     };
     // one 32-row block; OWNER 1: this tile holds the last label column and also publishes its scores;
     // OWNER 2 (shared fill): it holds watch columns, each in some lane at some k
-    auto block = [&](int j, auto owner_tag) {
+    auto block_impl = [&](int j, auto owner_tag, auto start_tag) {
         constexpr int OWNER = decltype(owner_tag)::value;
+        constexpr bool START = decltype(start_tag)::value;   // E1: some column of this tile is the start column or padding left of it
         const int slot = jslot;   // j % NS, kept by the block loop (NS is 3 or 4: a division otherwise)
         const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
         cur_slot = slot;
 #pragma unroll
         for (int k = 0; k < K; ++k) gaddr[k] += delta;
+        if constexpr (E1) xaddr += delta;
         // Owner tiles publish the score of their watched column after every row: ring entry q of the half (j & 1)
         // holds table row 32 j + q, so row i goes to entry i + 1 and the block's last row to entry 0 of the OTHER
         // half.  One ds_write_b32 per row straight from the register (every lane stores; the lanes that watch
@@ -753,11 +836,16 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // software pipeline: operands of row i+PF are requested while row i is computed
         constexpr int PF = CTCFA_PF;
         float2 emq[PF][K];
+        float eq[PF][K];   // E1: e alone ...
+        float2 xq[PF];     // ... and the row's (blank posterior, start-column stay step)
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
+            if constexpr (E1) xq[d] = *reinterpret_cast<const float2*>(smem + xaddr + d * ROW_BYTES);
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-                emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * (PITCH * 8));
+            for (int k = 0; k < K; ++k) {
+                if constexpr (E1) eq[d][k] = *reinterpret_cast<const float*>(smem + gaddr[k] + d * ROW_BYTES);
+                else emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * ROW_BYTES);
+            }
         }
 #pragma unroll
         for (int i = 0; i < kRows; ++i) {
@@ -770,12 +858,27 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 for (int k = 0; k < K; ++k) prev[k] = is_halo ? hx[k] : prev[k];
             }
             float2 em[K];
+            if constexpr (E1) {
+                const float2 xr = xq[i % PF];
 #pragma unroll
-            for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
-            if (i + PF < kRows) {
+                for (int k = 0; k < K; ++k) {
+                    const float e = eq[i % PF][k];
+                    em[k] = make_float2(e, max3f((START && startlike[k]) ? xr.y : xr.x, e, kProbMax));
+                }
+                if (i + PF < kRows) {
+                    xq[i % PF] = *reinterpret_cast<const float2*>(smem + xaddr + (i + PF) * ROW_BYTES);
 #pragma unroll
-                for (int k = 0; k < K; ++k)
-                    emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * (PITCH * 8));
+                    for (int k = 0; k < K; ++k)
+                        eq[i % PF][k] = *reinterpret_cast<const float*>(smem + gaddr[k] + (i + PF) * ROW_BYTES);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
+                if (i + PF < kRows) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * ROW_BYTES);
+                }
             }
             // lane 0 has no left neighbour: it is a halo lane (its first column goes wrong at once, by
             // design) or left padding (e = -inf: the sum loses whatever comes in)
@@ -886,6 +989,17 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         if constexpr (OWNER == 2) watch_out(j, true);
     };
 
+    // (only tile 0 holds the start column: the other tiles' code carries no select for it -- one vector instruction per
+    // cell less on the tiles that are waited for)
+    const bool tile_has_start = E1 && cbase - shift <= 0;
+    auto block = [&](int j, auto owner_tag) {
+        if constexpr (E1) {
+            if (tile_has_start) block_impl(j, owner_tag, std::true_type{});
+            else block_impl(j, owner_tag, std::false_type{});
+        } else {
+            block_impl(j, owner_tag, std::false_type{});
+        }
+    };
     for (int j = 0; j <= jlast; ++j, jslot = (jslot + 1 == NS) ? 0 : jslot + 1) {
         staged_seen = __builtin_amdgcn_readfirstlane(peek_sa < peek_sb ? peek_sa : peek_sb);
         if (__builtin_expect(staged_seen <= j, 0)) {   // emissions of block j (normally seen staged while block j-1 was computed)

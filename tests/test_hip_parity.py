@@ -143,7 +143,8 @@ def test_every_lane_tile_width(pkg, oracle, engine, K):
     plan.close()
 
 
-@pytest.mark.parametrize("V", [5, 29, 32, 33, 38, 40, 45, 48, 52, 56, 57, 63, 64, 65, 76, 80, 81, 96, 97, 100, 112, 113, 128])
+@pytest.mark.parametrize("V", [5, 29, 32, 33, 38, 40, 45, 48, 52, 56, 57, 63, 64, 65, 76, 80, 81, 96, 97, 100, 112, 113, 128, 129,
+                               150, 192, 193, 230, 256])
 def test_vocabulary_sizes(pkg, oracle, V):
     syn = pkg.synthetic
     segs = [syn.make_segment(200 + s + V, T, V, U, n) for s, (T, U, n) in
@@ -786,11 +787,11 @@ def test_wide_segments_in_a_full_batch(pkg, oracle, engine):
 
 
 @pytest.mark.parametrize("remap", [False, True], ids=["gather-kernel", "compact-remap"])
-@pytest.mark.parametrize("V,blank", [(129, 0), (500, 0), (1000, 37), (4096, 4095)])
+@pytest.mark.parametrize("V,blank", [(257, 0), (500, 0), (1000, 37), (4096, 4095)])
 def test_wide_vocabularies(pkg, oracle, monkeypatch, V, blank, remap):
-    """V > 128 (sub-word CTC models).  Default: the columns a segment can look at (its labels and the blank, at
-    most 128 per emission block) are gathered into a compact matrix and the staged kernels run on renumbered
-    labels (`state` comes back in the caller's ids).  CTCFA_NO_REMAP=1, or more than 127 distinct labels: the
+    """V > 256 (sub-word CTC models).  Default: the columns a segment can look at (its labels and the blank, at
+    most 256 per emission block) are gathered into a compact matrix and the staged kernels run on renumbered
+    labels (`state` comes back in the caller's ids).  CTCFA_NO_REMAP=1, or more than 255 distinct labels: the
     gather kernel -- no LDS staging of vocabulary rows, every lane gathers its own column's emission.
     Ragged batch incl. a segment with T < C and one with C = 2."""
     monkeypatch.setenv("CTCFA_NO_REMAP" if not remap else "CTCFA_REMAP", "1")
@@ -815,6 +816,29 @@ def test_wide_vocabularies(pkg, oracle, monkeypatch, V, blank, remap):
         _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
 
 
+@pytest.mark.parametrize("V", [100, 130, 200, 256])
+def test_vocabularies_of_65_to_256_entries_take_the_flags_and_long_texts(pkg, oracle, V):
+    """Above 64 entries the emission ring holds e alone and the tiles work out m = max(blank, e): every flag but
+    gratis_blank (checkpoint mode only), a blank that is not entry 0, texts beyond the gather kernel's 961 columns,
+    the windowed regime, shared emissions; one batch wide enough for several tiles with two columns per lane."""
+    rng = np.random.default_rng(30_000 + V)
+    blank = int(rng.integers(0, V))
+    segs = []
+    for U, n, T in ((9, 130, 3000), (12, 40, 1300), (3, 12, 150), (1, 2, 9), (5, 30, 100)):
+        gt, ub = pkg.synthetic.make_labels(rng, U, n, V, blank=blank)
+        segs.append((pkg.synthetic.make_emissions(rng, T, V, gt, blank=blank), gt, ub))
+    assert max(len(s[1]) for s in segs) > 961
+    for kw in (dict(blank=blank), dict(blank=blank, preamble_transition_cost_zero=False),
+               dict(blank=blank, backtrack_from_max_t=True, score_min_mean_over_L=9),
+               dict(blank=blank, min_window_size=400, max_window_size=6000)):
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+    lpz, gt, ub = segs[1]
+    members = [(lpz, gt[:ub[k] + 1].copy(), ub[:k + 1].copy()) for k in (12, 11, 9)]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR, blank=blank)
+    res = pkg.ctc_segmentation.get_segments_device(config, [lpz] * 3, [m[1] for m in members], [m[2] for m in members])
+    _check(pkg, oracle, members, res, cfg_kw=dict(blank=blank))
+
+
 def test_wide_vocabulary_long_label_sequences(pkg, oracle):
     """Up to 961 label columns (15 waves x 64 lanes) and the windowed regime with V = 300."""
     rng = np.random.default_rng(10_500)
@@ -832,10 +856,10 @@ def test_wide_vocabulary_long_label_sequences(pkg, oracle):
         _run(pkg, segs, preamble_transition_cost_zero=False)
 
 
-def test_blank_transition_cost_zero_between_65_and_128_entries(pkg, oracle):
+def test_blank_transition_cost_zero_between_65_and_256_entries(pkg, oracle):
     """gratis_blank exists in checkpoint mode only, which stages at most 64 vocabulary columns: a vocabulary of
-    65..128 entries takes it through the compact matrix when the launch looks at no more than 63 distinct labels."""
-    for V in (65, 100, 128):
+    65..256 entries takes it through the compact matrix when the launch looks at no more than 63 distinct labels."""
+    for V in (65, 100, 128, 200, 256):
         rng = np.random.default_rng(21_000 + V)
         blank = int(rng.integers(0, V))
         segs = []

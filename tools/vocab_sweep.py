@@ -14,7 +14,7 @@ syn = pkg.synthetic
 DUR = 320.4769 / 16000
 dev = torch.device("cuda:0")
 eng = pkg._native.Engine(0)
-for V in (20, 29, 32, 38, 48, 64, 76, 100, 128, 256):  # 256: the gather kernel (V > 128)
+for V in (20, 29, 32, 38, 48, 64, 76, 100, 128, 160, 192, 256, 300):  # 300: the gather kernel (V > 256)
     base = [syn.make_segment(s, 3000, V, 22, 28) for s in range(8)]
     segs = [base[i % 8] for i in range(512)]
     T = [s[0].shape[0] for s in segs]
