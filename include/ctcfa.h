@@ -53,7 +53,7 @@ extern "C" {
 #define CTCFA_ST_WINDOWED_UNSUPPORTED 3    /* windowed regime with T*4 bytes > LDS (T > ~40 000 frames) */
 #define CTCFA_ST_TEXT_TOO_LONG 4           /* more label columns than one fill workgroup covers
                                               (ctcfa_max_label_columns: 5 485 for a 32-entry vocabulary,
-                                              5 119 for the others up to 128, 961 above) with
+                                              5 119 for the others up to 256, 961 above) with
                                               T <= min_window_size; the other segments of the batch are aligned */
 #define CTCFA_ST_INTERNAL 5                /* a wave of the fill kernel gave up waiting for a progress
                                               counter (bounded spins: a bug must not hang the GPU) */
@@ -121,7 +121,8 @@ void ctcfa_default_params(ctcfa_params* p); /* CtcSegmentationParameters default
  * ctc_segmentation(): the `len(ground_truth) > lpz.shape[0]` assertion and the
  * `min(window_size, lpz.shape[0])` window decision become per-segment status.
  * force_cols_per_lane: 0 = launch-shape model, else K in {1,2,3,4,5,6,8,10,12,16}.
- * vocab <= 128: LDS-staged fill kernel.  vocab > 128 (sub-word models): gather kernel; needs
+ * vocab <= 256: LDS-staged fill kernel (above 80 entries the ring holds the emissions alone and the tiles work out
+ * max(blank, label) themselves).  vocab > 256 (sub-word models): gather kernel; needs
  * CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO and C <= 961, else CTCFA_ERR_UNSUPPORTED.
  */
 int ctcfa_plan_create(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params,
@@ -175,7 +176,7 @@ int ctcfa_plan_get_timings(ctcfa_plan* plan, int n, float* fill_ms, float* backt
  * runs, downloads and synchronises.  This is the call the reference-side binding
  * uses in place of `ctc_segmentation(config, lpz, ground_truth_mat)` +
  * `determine_utterance_segments(...)`.
- * Vocabularies above 128 entries (sub-word models): where no segment group looks at more than 128
+ * Vocabularies above 256 entries (sub-word models): where no segment group looks at more than 256
  * columns (its blank and distinct labels) and the text is long or the flags are not the package's
  * defaults, the call runs on a compact matrix of exactly those columns (labels renumbered inside,
  * `state` reported in the caller's ids); otherwise on the wide-vocabulary fill kernel, which is
@@ -212,7 +213,7 @@ int ctcfa_align_batch_resident(ctcfa_engine* eng, const ctcfa_params* params, in
  * Members of an emission group whose label sequence is a proper prefix of the group's longest aligned
  * member are served by that member's fill (column c of the trellis depends on columns <= c only): one
  * fill, one backtrack + scoring per member, results identical to separate calls.  Other members
- * (different text, equal length, status != 0, vocab > 128, T > min_window_size, more than 15 prefixes,
+ * (different text, equal length, status != 0, vocab > 256, T > min_window_size, more than 15 prefixes,
  * two prefixes ending in the same lane) are filled by themselves over the shared emissions -- and so
  * is every member when the batch needs fill tiles wider than two columns per lane (texts of more than
  * ~1 700 label columns: only the one- and two-column tiles carry the "watch column" variant of the row

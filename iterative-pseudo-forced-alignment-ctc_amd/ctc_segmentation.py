@@ -219,7 +219,7 @@ def _raise_for_status(status, error=None):
         raise NotImplementedError("windowed DP regime with more than ~40 000 frames (one column must fit the LDS)")
     if status == _native.ST_TEXT_TOO_LONG:
         raise NotImplementedError("more label columns than one workgroup of the fill kernel covers "
-                                  "(ctcfa_max_label_columns: 5 485 for a 32-entry vocabulary, 5 119 for the others up to 128)")
+                                  "(ctcfa_max_label_columns: 5 485 for a 32-entry vocabulary, 5 119 for the others up to 256)")
     if status != _native.ST_OK:
         raise RuntimeError(f"ctcfa status {status}")
 
