@@ -363,6 +363,14 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
             if (want * r512(lds_bytes_fill(4, W, K, VP, nwatch)) + 2 * r512(lds_beside) > lds_limit &&
                 want * r512(lds_bytes_fill(3, W, K, VP, nwatch)) + 2 * r512(lds_beside) <= lds_limit)
                 NS = 3;
+            // ... or the workgroups alone: 192 entries 103 KB with four slots, 78 KB with three -- two on a CU, 465 -> 320 us;
+            // 256 entries 135 / 102 / 70 KB with four / three / two: 543 -> 383 us with two (where both fit, fewer slots are
+            // slower: 32 entries 140 -> 163 us, 128 entries 298 -> 328)
+            const int g4 = lds_limit / r512(lds_bytes_fill(4, W, K, VP, nwatch));
+            const int g3 = lds_limit / r512(lds_bytes_fill(3, W, K, VP, nwatch));
+            const int g2 = lds_limit / r512(lds_bytes_fill(2, W, K, VP, nwatch));
+            if (g4 < want && g3 > g4) NS = 3;
+            if (g3 < want && g2 > g3) NS = 2;
             if (lds_bytes_fill(NS, W, K, VP, nwatch) > lds_limit) NS = 3;
         }
         const int lds = lds_bytes_fill(NS, W, K, VP, nwatch);
