@@ -17,6 +17,7 @@
 #include <hip/hip_ext.h>
 
 #include "../../include/ctcfa.h"
+#include "ctcfa_fill_select.hip.h"
 
 using ctcfa::BtParams;
 using ctcfa::SegDesc;
@@ -145,38 +146,23 @@ struct DeviceGuard {
             return set_err(eng, CTCFA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-using FillFn = void (*)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                        const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int);
-
-template <int VP, bool CK>
-FillFn fill_for_k(int K) {
-    switch (K) {
-        case 1: return ctcfa::fill_kernel<1, VP, CK>;
-        case 2: return ctcfa::fill_kernel<2, VP, CK>;
-        case 3: return ctcfa::fill_kernel<3, VP, CK>;
-        case 4: return ctcfa::fill_kernel<4, VP, CK>;
-        case 5: return ctcfa::fill_kernel<5, VP, CK>;
-        case 6: return ctcfa::fill_kernel<6, VP, CK>;
-        case 8: return ctcfa::fill_kernel<8, VP, CK>;
-        case 10: return ctcfa::fill_kernel<10, VP, CK>;
-        case 12: return ctcfa::fill_kernel<12, VP, CK>;
-        case 16: return ctcfa::fill_kernel<16, VP, CK>;
-        default: return nullptr;
-    }
-}
-
-template <int VP>
-FillFn fill_any(int K, bool ck) {
-    if constexpr (VP <= 64) {
-        if (ck) return fill_for_k<VP, true>(K);
-    }
-    return fill_for_k<VP, false>(K);
-}
-
 FillFn select_fill(int K, int VP, bool ck) {
     switch (VP) {
         case 32: return fill_any<32>(K, ck);
-#ifndef CTCFA_DEV_VP32_ONLY  // tuning builds (tools/build_variant.sh): one pitch compiles in a fifth of the time
+#if defined(CTCFA_DEV_VP32_ONLY)   // tuning builds (tools/build_variant.sh): one pitch compiles in a fifth of the time
+#if defined(CTCFA_DEV_WIDE)        // (... of the wide pitches)
+        case 128: return fill_any<128>(K, ck);
+        case 256: return fill_any<256>(K, ck);
+#endif
+#elif defined(CTCFA_SPLIT_BUILD)   // __graft_entry__.build(): the other pitches are compiled beside this file, in parallel
+        case 40: return ctcfa_fill_group_1(K, VP, ck);
+        case 48: return ctcfa_fill_group_2(K, VP, ck);
+        case 56: return ctcfa_fill_group_3(K, VP, ck);
+        case 64: return ctcfa_fill_group_4(K, VP, ck);
+        case 80: case 96: case 112: return ctcfa_fill_group_5(K, VP, ck);
+        case 128: case 160: return ctcfa_fill_group_6(K, VP, ck);
+        case 192: case 256: return ctcfa_fill_group_7(K, VP, ck);
+#else                              // one translation unit (hipcc ctcfa.hip): everything here
         case 40: return fill_any<40>(K, ck);
         case 48: return fill_any<48>(K, ck);
         case 56: return fill_any<56>(K, ck);
@@ -187,9 +173,6 @@ FillFn select_fill(int K, int VP, bool ck) {
         case 128: return fill_any<128>(K, ck);
         case 160: return fill_any<160>(K, ck);
         case 192: return fill_any<192>(K, ck);
-        case 256: return fill_any<256>(K, ck);
-#elif defined(CTCFA_DEV_WIDE)   // (tuning builds of the wide pitches)
-        case 128: return fill_any<128>(K, ck);
         case 256: return fill_any<256>(K, ck);
 #endif
         default: return nullptr;

@@ -1067,6 +1067,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     }
 }
 
+#ifndef CTCFA_FILL_KERNEL_ONLY   // (ctcfa_fill_pitches.hip: translation units that hold instantiations of fill_kernel and nothing else)
+
 // ---------------------------------------------------------------------------------------
 // Fill kernel for wide vocabularies (V > 128: sub-word CTC models).  A vocabulary row no longer
 // fits an LDS ring, so nothing is staged: every lane owns ONE label column (K = 1) and gathers
@@ -2760,4 +2762,5 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
                                   seg_start, seg_end, seg_score);
 }
 
+#endif  // CTCFA_FILL_KERNEL_ONLY
 }  // namespace ctcfa
