@@ -231,10 +231,10 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const bool preamble = (cost_flags & 1) != 0;
     const bool gratis = (cost_flags & 2) != 0;
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool E1 = VP > 80;           // the ring holds e alone (4 B an entry), the tiles work out m: see the producers
+    constexpr bool E_ALONE = VP > 80;           // the ring holds e alone (4 B an entry), the tiles work out m: see the producers
     static_assert(!(VP > 64 && CK), "checkpoint mode exists for vocabularies of at most 64 entries");
-    constexpr int PITCH = E1 ? VP + 4 : VP + kPitchPad;  // row pitch in entries; entry VP = start-column pseudo label
-    constexpr int ROW_BYTES = PITCH * (E1 ? 4 : 8);
+    constexpr int PITCH = E_ALONE ? VP + 4 : VP + kPitchPad;  // row pitch in entries; entry VP = start-column pseudo label
+    constexpr int ROW_BYTES = PITCH * (E_ALONE ? 4 : 8);
     constexpr int SLOT_BYTES = kRows * ROW_BYTES;
     constexpr int HL = halo_lanes(K);      // halo lanes of a tile
     constexpr int XW = HL * K;             // floats per exchange row
@@ -328,7 +328,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // blank_transition_cost_zero: the blank entry's stay step of the rows this wave just staged becomes 0
             // (one store per block, after the rows' own stores -- LDS executes a wave's operations in order; nothing
             // in the per-row code, so nothing in the way when the flag is off)
-            if (!E1 && gratis) {   // (the plan refuses the flag above 64 entries)
+            if (!E_ALONE && gratis) {   // (the plan refuses the flag above 64 entries)
                 // the rows of the block this wave staged: all of them; every other one; every other group of four
                 const int nmine = roles->nprod == 2 ? kRows / 2 : kRows;
                 const int row = roles->nprod != 2 ? lane : fix_mode == 2 ? ((lane >> 2) * 2 + part) * 4 + (lane & 3)
@@ -549,7 +549,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 write_chunk(jb + 1, p0, eb);
                 publish(jb + 1);
             }
-        } else if constexpr (VP > 64 && !E1) {
+        } else if constexpr (VP > 64 && !E_ALONE) {
             // ---- character vocabularies between 65 and 80 entries (e.g. 76 for French), (e, m) pairs as below 64: a row per
             // pass, lane i holds entries i and 64 + i; lane 0 also writes the start-column pseudo entry.
             // Two producers, each stages every other row.  Under preamble_transition_cost_zero the start-column entry
@@ -605,7 +605,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     *reinterpret_cast<float2*>(smem + static_cast<uint32_t>((idx / kRows) * SLOT_BYTES + (idx % kRows) * (PITCH * 8) + VP * 8)) =
                         make_float2(-__builtin_inff(), 0.0f);
             runw(std::integral_constant<int, 2>{});   // (the plan always gives these vocabularies two producers)
-        } else if constexpr (E1) {
+        } else if constexpr (E_ALONE) {
             // ---- vocabularies of 81 .. 256 entries (character sets like French's 76, small sub-word models): the ring
             // holds the emissions alone, one float per entry (e only: a row of (e, m) pairs is 2 x 8 B x VP -- random
             // labels then meet in the same LDS banks three or four deep, and one workgroup takes most of a CU's LDS);
@@ -689,9 +689,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     float prev[K];
     float hx[K];        // halo values to put in at the start of the next group
     uint32_t dec[K];
-    uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair (E1: of its e) in row 0 of the current slot
-    bool startlike[K];  // E1: the start column or padding left of it (its m comes from entry VP + 3 of the row)
-    uint32_t xaddr = static_cast<uint32_t>((VP + 2) * 4);   // E1: the row's (blank, start-column stay step) pair, same bookkeeping as gaddr
+    uint32_t gaddr[K];  // LDS byte address of this column's (e, m) pair (E_ALONE: of its e) in row 0 of the current slot
+    bool startlike[K];  // E_ALONE: the start column or padding left of it (its m comes from entry VP + 3 of the row)
+    uint32_t xaddr = static_cast<uint32_t>((VP + 2) * 4);   // E_ALONE: the row's (blank, start-column stay step) pair, same bookkeeping as gaddr
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int pc = cbase + lane * K + k;
@@ -700,7 +700,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         if (c <= 0) lab = VP;                  // start column / left padding
         else if (c < C) lab = seg_lab[c];
         else lab = blank;                      // right padding: any valid entry
-        gaddr[k] = static_cast<uint32_t>(lab) * (E1 ? 4u : 8u);
+        gaddr[k] = static_cast<uint32_t>(lab) * (E_ALONE ? 4u : 8u);
         startlike[k] = c <= 0;
         prev[k] = (c <= 0) ? 0.0f : kProbMax;  // table[0,0] = 0, table[0,c>0] = -1e9
         hx[k] = prev[k];
@@ -811,13 +811,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // OWNER 2 (shared fill): it holds watch columns, each in some lane at some k
     auto block_impl = [&](int j, auto owner_tag, auto start_tag) {
         constexpr int OWNER = decltype(owner_tag)::value;
-        constexpr bool START = decltype(start_tag)::value;   // E1: some column of this tile is the start column or padding left of it
+        constexpr bool START = decltype(start_tag)::value;   // E_ALONE: some column of this tile is the start column or padding left of it
         const int slot = jslot;   // j % NS, kept by the block loop (NS is 3 or 4: a division otherwise)
         const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
         cur_slot = slot;
 #pragma unroll
         for (int k = 0; k < K; ++k) gaddr[k] += delta;
-        if constexpr (E1) xaddr += delta;
+        if constexpr (E_ALONE) xaddr += delta;
         // Owner tiles publish the score of their watched column after every row: ring entry q of the half (j & 1)
         // holds table row 32 j + q, so row i goes to entry i + 1 and the block's last row to entry 0 of the OTHER
         // half.  One ds_write_b32 per row straight from the register (every lane stores; the lanes that watch
@@ -836,14 +836,14 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // software pipeline: operands of row i+PF are requested while row i is computed
         constexpr int PF = CTCFA_PF;
         float2 emq[PF][K];
-        float eq[PF][K];   // E1: e alone ...
+        float eq[PF][K];   // E_ALONE: e alone ...
         float2 xq[PF];     // ... and the row's (blank posterior, start-column stay step)
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            if constexpr (E1) xq[d] = *reinterpret_cast<const float2*>(smem + xaddr + d * ROW_BYTES);
+            if constexpr (E_ALONE) xq[d] = *reinterpret_cast<const float2*>(smem + xaddr + d * ROW_BYTES);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if constexpr (E1) eq[d][k] = *reinterpret_cast<const float*>(smem + gaddr[k] + d * ROW_BYTES);
+                if constexpr (E_ALONE) eq[d][k] = *reinterpret_cast<const float*>(smem + gaddr[k] + d * ROW_BYTES);
                 else emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * ROW_BYTES);
             }
         }
@@ -858,7 +858,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 for (int k = 0; k < K; ++k) prev[k] = is_halo ? hx[k] : prev[k];
             }
             float2 em[K];
-            if constexpr (E1) {
+            if constexpr (E_ALONE) {
                 const float2 xr = xq[i % PF];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -991,9 +991,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 
     // (only tile 0 holds the start column: the other tiles' code carries no select for it -- one vector instruction per
     // cell less on the tiles that are waited for)
-    const bool tile_has_start = E1 && cbase - shift <= 0;
+    const bool tile_has_start = E_ALONE && cbase - shift <= 0;
     auto block = [&](int j, auto owner_tag) {
-        if constexpr (E1) {
+        if constexpr (E_ALONE) {
             if (tile_has_start) block_impl(j, owner_tag, std::true_type{});
             else block_impl(j, owner_tag, std::false_type{});
         } else {
