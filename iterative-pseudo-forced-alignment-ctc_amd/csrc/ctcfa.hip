@@ -61,6 +61,7 @@ struct ctcfa_plan {
     ctcfa_params prm{};
     int B = 0, V = 0, K = 0, W = 0, VP = 0;
     int lds_fill = 0, lds_bt = 0, rec_bytes = 0, lab_bytes = 0, nblk_max = 0;
+    bool overlap_ok = true;   // a backtrack workgroup of the previous run fits a CU beside this plan's fill workgroups
     bool ckpt = false;  // fill stores table rows, the backtrack recomputes its decisions (V <= 64)
     int bt_waves = 4;   // waves of a backtrack workgroup (checkpoint mode: striders, one 32-row block each)
     int bt_scorers = 0; // ... plus waves that only score utterances (checkpoint mode, plans with utterances)
@@ -338,22 +339,28 @@ bool pick_shape(int B, int Cmax, int VP, int lds_limit, int lds_beside, int num_
         const int W = (Cmax + (K - 1) + U - 1) / U;   // (the left padding can take up to K-1 columns)
         const int waves_per_wg = waves_of(W, nprod);
         if (!shape_launchable(K, W, nprod)) continue;
-        // Ring slots: 4 (the producer up to three blocks ahead of the tiles); 3 when that is what lets the
-        // workgroups a CU needs, and two backtrack workgroups of the previous batch, share its LDS.
+        // Ring slots: 4 (the producer up to three blocks ahead of the tiles) unless fewer are what lets the workgroups a CU
+        // needs share its LDS with backtrack workgroups of the previous batch (the pipelined schedule) -- with two of them
+        // (3 slots), else with one (3, then 2 slots: 64 entries 0.279 -> 0.213 ms per pipelined step with three slots and
+        // one backtrack workgroup beside, 56 entries 0.257 -> 0.218, 192 entries 0.477 -> 0.402 with two slots) -- or, where
+        // no backtrack fits beside anyway, with each other: 192 entries 103 / 78 KB with four / three slots (465 -> 330 us
+        // alone), 256 entries 135 / 102 / 70 KB with four / three / two (543 -> 388 us).  Where everything fits, fewer slots
+        // are slower (32 entries 140 -> 163 us with two, 128 entries 298 -> 328).
         int NS = ns_forced ? ns_forced : 4;
         if (!ns_forced) {
             const int want = std::min(wg_per_cu_needed, 2);
-            if (want * r512(lds_bytes_fill(4, W, K, VP, nwatch)) + 2 * r512(lds_beside) > lds_limit &&
-                want * r512(lds_bytes_fill(3, W, K, VP, nwatch)) + 2 * r512(lds_beside) <= lds_limit)
-                NS = 3;
-            // ... or the workgroups alone: 192 entries 103 KB with four slots, 78 KB with three -- two on a CU, 465 -> 320 us;
-            // 256 entries 135 / 102 / 70 KB with four / three / two: 543 -> 383 us with two (where both fit, fewer slots are
-            // slower: 32 entries 140 -> 163 us, 128 entries 298 -> 328)
-            const int g4 = lds_limit / r512(lds_bytes_fill(4, W, K, VP, nwatch));
-            const int g3 = lds_limit / r512(lds_bytes_fill(3, W, K, VP, nwatch));
-            const int g2 = lds_limit / r512(lds_bytes_fill(2, W, K, VP, nwatch));
-            if (g4 < want && g3 > g4) NS = 3;
-            if (g3 < want && g2 > g3) NS = 2;
+            auto fits = [&](int ns, int nbt) {
+                return want * r512(lds_bytes_fill(ns, W, K, VP, nwatch)) + nbt * r512(lds_beside) <= lds_limit;
+            };
+            auto groups = [&](int ns) { return lds_limit / r512(lds_bytes_fill(ns, W, K, VP, nwatch)); };
+            if (fits(4, 2)) NS = 4;
+            else if (fits(3, 2)) NS = 3;
+            else if (fits(4, 1)) NS = 4;
+            else if (fits(3, 1)) NS = 3;
+            else if (fits(2, 1)) NS = 2;
+            else if (groups(4) >= want) NS = 4;
+            else if (groups(3) > groups(4)) NS = groups(3) >= want || groups(2) <= groups(3) ? 3 : 2;
+            else if (groups(2) > groups(4)) NS = 2;
             if (lds_bytes_fill(NS, W, K, VP, nwatch) > lds_limit) NS = 3;
         }
         const int lds = lds_bytes_fill(NS, W, K, VP, nwatch);
@@ -691,8 +698,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                           (use_scratch ? nf * Cmax >= 1024 * 1024
                                        : Cmax >= 544 || Tmax >= 900 || (nf * Cmax >= 250000 && Tmax >= 1000 && Cmax >= 192));
         // (57..64 entries: a strider's LDS slot is 8 KB and only ONE backtrack workgroup fits a CU beside two fill
-        // workgroups -- pipelined 0.281 ms per step against 0.269 with decision words, 0.240 with round 2's 15.8 KB
-        // backtrack; one stream after the other checkpoint mode is 20 % ahead, so it stays)
+        // workgroups, with a ring of three slots -- pick_shape: 0.213 ms per pipelined step, 0.240 with round 2's 15.8 KB
+        // backtrack, 0.272 with decision words)
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
         if (gratis) pl->ckpt = true;   // (vocab <= 64 checked above)
     }
@@ -919,6 +926,17 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             PLAN_TRY(hipMalloc(&pl->d_watch, sizeof(ctcfa::WatchDesc) * pl->watch.size()));
             PLAN_TRY(hipMemcpy(pl->d_watch, pl->watch.data(), sizeof(ctcfa::WatchDesc) * pl->watch.size(), hipMemcpyHostToDevice));
         }
+    }
+    {   // The pipelined entry runs the backtrack of run k beside the fill of run k+1 -- where one fits beside the other.
+        // Where not a single backtrack workgroup finds LDS (or registers: the 256-entry kernels take 128, two workgroups
+        // fill the register file) next to the fill workgroups a CU holds, the two kernels only get in each other's way and
+        // the entry runs them one after the other instead.  Measured, config 3's shape, ms per step pipelined | serial:
+        // 56 entries 0.257 | 0.249, 64: 0.279 | 0.265, 192: 0.477 | 0.424, 256: 0.563 | 0.491 -- against 38: 0.177 | 0.244,
+        // 48: 0.201 | 0.244, 76: 0.287 | 0.362, 128: 0.328 | 0.397, 160: 0.374 | 0.416 where one fits.
+        auto r512 = [](int v) { return (v + 511) / 512 * 512; };
+        const int fill_per_cu = std::min(2, std::max(1, (n_fill_of() + eng->num_cu - 1) / eng->num_cu));
+        pl->overlap_ok = gather || (fill_per_cu * r512(pl->lds_fill) + r512(pl->lds_bt) <= eng->lds_limit && pl->VP < 256);
+        if (std::getenv("CTCFA_ALWAYS_OVERLAP")) pl->overlap_ok = true;
     }
     if (pl->lds_fill > 48 * 1024 && pl->fill_fn)
         PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fill_fn),
@@ -1184,9 +1202,13 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* pl, const float* d_lpz, const int32_t* 
     // the events ride on the kernels' own dispatch packets: nothing else enters the queues
     hipEvent_t fill_done = ev ? ev[1] : pl->ev_fill_done[q];
     if ((rc = launch_fill(pl, a, q, st, ev ? ev[0] : nullptr, fill_done)) != CTCFA_OK) return rc;
-    HIP_TRY(eng, hipStreamWaitEvent(pl->side, fill_done, 0));
     hipEvent_t bt_done = ev ? ev[3] : pl->ev_bt_done[q];
-    if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side, ev ? ev[2] : nullptr, bt_done, true)) != CTCFA_OK) return rc;
+    if (pl->overlap_ok) {
+        HIP_TRY(eng, hipStreamWaitEvent(pl->side, fill_done, 0));
+        if ((rc = launch_backtrack(pl, a, want_seg, q, pl->side, ev ? ev[2] : nullptr, bt_done, true)) != CTCFA_OK) return rc;
+    } else {   // (no room beside the next fill: behind this one, in the caller's stream)
+        if ((rc = launch_backtrack(pl, a, want_seg, q, st, ev ? ev[2] : nullptr, bt_done, false)) != CTCFA_OK) return rc;
+    }
     if (ev) pl->ev_runs++;
     pl->bt_done_ev[q] = bt_done;
     pl->bt_pending[q] = true;
