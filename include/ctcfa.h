@@ -153,6 +153,9 @@ int ctcfa_plan_run_device(ctcfa_plan* plan, const float* d_lpz, const int32_t* d
  * enters `stream`.  Outputs of a call are complete on `stream` only after
  * ctcfa_plan_flush(plan, stream), which makes `stream` wait for every outstanding backtrack;
  * give consecutive calls different output buffers.  Same arguments as ctcfa_plan_run_device.
+  * Where not a single backtrack workgroup finds room on a CU beside the plan's fill workgroups (LDS, registers:
+ * vocabularies of 193+ entries, ...), the entry keeps its contract but runs the two kernels one after the other in
+ * the caller's stream: side by side they would only slow each other down.
  */
 int ctcfa_plan_run_pipelined(ctcfa_plan* plan, const float* d_lpz, const int32_t* d_labels,
                              const int32_t* d_utt_begin, int32_t* d_frame_of_label,
