@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--vocab", type=int, default=32)
     ap.add_argument("--utts", type=int, default=22)
     ap.add_argument("--utt-len", type=int, default=28)
+    ap.add_argument("--alphabet", type=int, default=0,
+                    help="synthetic: the texts use the first N non-blank vocabulary entries only (a character model's vocabulary "
+                         "holds more symbols than its texts show: --vocab 38 --alphabet 28 fills in 150 us where 37 random labels take 176)")
     ap.add_argument("--cols-per-lane", type=int, default=int(os.environ.get("CTCFA_K", "0")))
     ap.add_argument("--cpu-sample", type=int, default=512, help="segments timed on the CPU oracle (0 = skip)")
     ap.add_argument("--spinup-steps", type=int, default=1024,
@@ -473,7 +476,7 @@ def main():
     # ---- synthetic workload (SURVEY §8(d) recipe), this rank's shard ----------------------
     syn = pkg.synthetic
     B, T, V, U, n = args.segments, args.frames, args.vocab, args.utts, args.utt_len
-    lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, seed0=rank * B)
+    lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, seed0=rank * B, alphabet=args.alphabet or None)
     C = gt.shape[1]
     cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
     cfg.backtrack_from_max_t = bool(args.from_max_t)

@@ -10,15 +10,16 @@ columns laid out the way ``prepare_token_list`` lays them out
 import numpy as np
 
 
-def make_labels(rng, n_utts, utt_len, vocab, blank=0):
-    """-> (gt int64 [C], utt_begin int64 [U+1]) with C = 1 + U*(1+n) + 1."""
+def make_labels(rng, n_utts, utt_len, vocab, blank=0, alphabet=None):
+    """-> (gt int64 [C], utt_begin int64 [U+1]) with C = 1 + U*(1+n) + 1.  ``alphabet``: the texts use the first
+    ``alphabet`` non-blank entries only (a character model's vocabulary holds more symbols than its texts show)."""
     gt = [-1]
     utt_begin = []
     for _ in range(n_utts):
         if gt[-1] != blank:
             gt.append(blank)
         utt_begin.append(len(gt) - 1)
-        ids = rng.integers(1, vocab, size=utt_len)
+        ids = rng.integers(1, vocab if alphabet is None else min(vocab, alphabet + 1), size=utt_len)
         if blank != 0:
             ids = np.where(ids == blank, 0, ids)
         gt.extend(int(i) for i in ids)
@@ -50,16 +51,16 @@ def make_emissions(rng, n_frames, vocab, gt, blank=0, noise=3.0, peak=6.0):
     return (z - lse).astype(np.float32)
 
 
-def make_segment(seed, n_frames, vocab, n_utts, utt_len, blank=0):
+def make_segment(seed, n_frames, vocab, n_utts, utt_len, blank=0, alphabet=None):
     """One (lpz, gt, utt_begin) triple; seeds follow SURVEY §8(d): 1234+b / 4321+b."""
-    gt, utt_begin = make_labels(np.random.default_rng(4321 + seed), n_utts, utt_len, vocab, blank)
+    gt, utt_begin = make_labels(np.random.default_rng(4321 + seed), n_utts, utt_len, vocab, blank, alphabet)
     lpz = make_emissions(np.random.default_rng(1234 + seed), n_frames, vocab, gt, blank)
     return lpz, gt, utt_begin
 
 
-def make_uniform_batch(batch, n_frames, vocab, n_utts, utt_len, seed0=0, blank=0):
+def make_uniform_batch(batch, n_frames, vocab, n_utts, utt_len, seed0=0, blank=0, alphabet=None):
     """-> lpz [B,T,V] f32, gt [B,C] i64, utt_begin [B,U+1] i64."""
-    segs = [make_segment(seed0 + b, n_frames, vocab, n_utts, utt_len, blank) for b in range(batch)]
+    segs = [make_segment(seed0 + b, n_frames, vocab, n_utts, utt_len, blank, alphabet) for b in range(batch)]
     return (np.stack([s[0] for s in segs]), np.stack([s[1] for s in segs]),
             np.stack([s[2] for s in segs]))
 
