@@ -149,3 +149,14 @@ def test_every_task_keeps_its_own_timing_config(pkg):
     assert a.config is not b.config
     assert a.config.index_duration == pytest.approx(16000 / 50 / 16000)
     assert b.config.index_duration == pytest.approx(32000 / 50 / 16000)
+
+
+def test_synthetic_labels_over_an_alphabet(pkg):
+    """bench.py --alphabet: texts that use the first N non-blank entries of a larger vocabulary."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    gt, ub = pkg.synthetic.make_labels(rng, 4, 50, 38, blank=0, alphabet=28)
+    assert gt[0] == -1 and gt[1:].min() >= 0 and gt[1:].max() <= 28
+    assert len(np.unique(gt[1:])) > 20 and len(ub) == 5
+    lpz, gt2, ub2 = pkg.synthetic.make_segment(7, 400, 38, 3, 20, alphabet=28)
+    assert lpz.shape == (400, 38) and gt2[1:].max() <= 28
