@@ -75,12 +75,42 @@ def parse():
     ap.add_argument("--from-max-t", action="store_true",
                     help="backtrack_from_max_t: every path ends in the last frame (the longest backtrack); "
                          "the default recipe's paths end near frame 1950 of 3000")
+    ap.add_argument("--input-sets", type=int, default=4,
+                    help="synthetic: distinct emission / label sets in HBM, one per step in rotation (4 x 197 MB = 788 MB > the "
+                         "256 MiB Infinity Cache: every step's emissions come from HBM, not from the MALL)")
+    ap.add_argument("--check-segments", type=int, default=32,
+                    help="synthetic: segments of EACH of the last two timed steps (two different input sets) compared with the oracle")
     ap.add_argument("--no-check", action="store_true",
                     help="kernel-tuning only: skip the status/parity gate (ablated builds give wrong results)")
     return ap.parse_args()
 
 
-def roofline_entry(fill_ms, bt_ms, ms_per_step, stride, fill_bytes, step_bytes, default_workload):
+def issue_entry(kernel_ms_avg, rows, cols_per_lane, tiles_per_simd):
+    """The kernel's OTHER ceiling ("VALU utilisation is reported beside it"): the fill is bound by
+    instruction issue, not by HBM.  `valu` = SQ counters of the fill kernel reduced per launch (tools/collect_issue.sh ->
+    profiles/r*_fill_issue.json); `issue_floor_ms` = trellis rows x the time one row of the SAME row loop takes in
+    isolation (tools/row_rate: same ISA, `tiles_per_simd` waves per SIMD, nothing to wait for), `issue_frac` = that floor
+    over the measured kernel time."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fill_issue.json")))
+    if not files:
+        return {}
+    try:
+        j = json.load(open(files[-1]))
+        rr = j["row_rate"]
+        key = "K%d_w%d" % (cols_per_lane, max(1, min(4, tiles_per_simd)))
+        ns_row = rr["ns_per_row"][key]
+        floor_ms = rows * ns_row * 1e-6
+        return {"valu": dict(j["valu"], source="profiles/" + os.path.basename(files[-1])),
+                "issue_floor_ms": floor_ms, "issue_frac": floor_ms / kernel_ms_avg,
+                "issue_floor_note": "%d rows x %.1f ns (%s cycles) per row of the isolated row loop at %d tile waves per SIMD (tools/row_rate, %s)"
+                                    % (rows, ns_row, rr["cycles_per_row"].get(key), tiles_per_simd, key)}
+    except Exception as exc:   # (a profile of another shape: no figure rather than a wrong one)
+        return {"issue_note": "no issue-floor figure: " + repr(exc)}
+
+
+def roofline_entry(fill_ms, bt_ms, ms_per_step, stride, fill_bytes, step_bytes, default_workload, input_sets=1,
+                   rows=0, cols_per_lane=0, serial=False, tiles_per_simd=3, emission_bytes=0):
     """The `roofline` object.  `achieved` / `frac` belong to the DOMINANT KERNEL: the fill's own
     algorithmic bytes (emissions read once, 4TV, + the 1-bit-per-cell trace written once, TC/8) over the
     fill's own average launch duration.  `step_*` is the whole step: SURVEY section 8(d)'s per-segment figure
@@ -106,9 +136,15 @@ def roofline_entry(fill_ms, bt_ms, ms_per_step, stride, fill_bytes, step_bytes, 
             src = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 FETCH x2)"
         except Exception:
             traffic = None
+    issue = issue_entry(float(np.mean(fill_ms)), rows, cols_per_lane, tiles_per_simd) if (rows and default_workload) else {}
+    resident = input_sets * (emission_bytes or fill_bytes)
     return {"bound": "hbm", "kernel": "ctcfa::fill_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": detail, "traffic_source": src,
-            "traffic_note": "fabric bytes (Infinity-Cache hits included): the bench re-reads the same emissions every step, under the 256 MiB MALL",
+            "traffic_note": ("%d input sets in rotation: %.0f MB of emissions between two uses of the same bytes, %s the 256 MiB "
+                             "Infinity Cache -- %s" % (input_sets, resident / 1e6, "beyond" if resident > 268e6 else "UNDER",
+                                                       "the reads cross HBM" if resident > 268e6 else
+                                                       "fabric bytes, MALL hits included")),
+            **issue,
             "algorithmic_bytes_per_launch": fill_bytes,
             "algorithmic_bytes_note": "fill kernel only: 4TV + TC/8 per segment (the whole step, backtrack included: step_algorithmic_bytes)",
             "kernel_ms_avg": float(np.mean(fill_ms)), "kernel_ms_min": float(np.min(fill_ms)),
@@ -386,16 +422,23 @@ def spawn_ranks(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    # rank 0's stdout goes to a file, not a pipe: nobody has to drain it while the ranks run (a library that prints more
+    # than a pipe buffer would otherwise block rank 0 in write() and the others in the rendezvous)
+    out0_file = tempfile.TemporaryFile(prefix="ctcfa_rank0_")
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CTCFA_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], cwd=ROOT, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
     # (a rank that dies before the first barrier would leave the others waiting in the rendezvous for ever: the
-    # launcher watches its own children and ends the rest -- exactly these processes -- when one fails)
+    # launcher watches its own children and ends the rest -- exactly these processes -- when one fails, or when the
+    # whole job overruns CTCFA_BENCH_TIMEOUT seconds)
     import time
+    deadline = time.monotonic() + float(os.environ.get("CTCFA_BENCH_TIMEOUT", "1500"))
+    timed_out = False
     while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):
+        timed_out = time.monotonic() > deadline
+        if timed_out or any(p.poll() not in (None, 0) for p in procs):
             for p in procs:
                 if p.poll() is None:
                     p.terminate()
@@ -408,7 +451,12 @@ def spawn_ranks(args):
         except subprocess.TimeoutExpired:
             p.kill()
             rcs.append(p.wait())
-    out0 = procs[0].stdout.read().decode()
+    out0_file.seek(0)
+    out0 = out0_file.read().decode(errors="replace")
+    out0_file.close()
+    if timed_out:
+        sys.stderr.write("bench.py: the ranks overran CTCFA_BENCH_TIMEOUT and were ended\n")
+        rcs = [rc or 124 for rc in rcs]
     if cpu_file:
         os.unlink(cpu_file)
     # (ONE JSON line on stdout: what libraries of rank 0 may have printed there -- gloo announces its peers -- goes to stderr)
@@ -476,7 +524,11 @@ def main():
     # ---- synthetic workload (SURVEY §8(d) recipe), this rank's shard ----------------------
     syn = pkg.synthetic
     B, T, V, U, n = args.segments, args.frames, args.vocab, args.utts, args.utt_len
-    lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, seed0=rank * B, alphabet=args.alphabet or None)
+    NIN = max(1, args.input_sets)
+    # input set k of rank r: seeds (r + 64 k) B ... -- set 0 is the recipe's own batch
+    host_sets = [syn.make_uniform_batch(B, T, V, U, n, seed0=(rank + 64 * k) * B, alphabet=args.alphabet or None)
+                 for k in range(NIN)]
+    lpz, gt, ub = host_sets[0]
     C = gt.shape[1]
     cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
     cfg.backtrack_from_max_t = bool(args.from_max_t)
@@ -484,9 +536,8 @@ def main():
     plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane)
     info = plan.info
 
-    d_lpz = torch.from_numpy(lpz.reshape(-1)).to(dev)
-    d_lab = torch.from_numpy(gt.astype(np.int32).reshape(-1)).to(dev)
-    d_ub = torch.from_numpy(ub.astype(np.int32).reshape(-1)).to(dev)
+    d_in = [(torch.from_numpy(h[0].reshape(-1)).to(dev), torch.from_numpy(h[1].astype(np.int32).reshape(-1)).to(dev),
+             torch.from_numpy(h[2].astype(np.int32).reshape(-1)).to(dev)) for h in host_sets]
     def alloc_outputs():
         return dict(fol=torch.empty(B * C, dtype=torch.int32, device=dev),
                     cp=torch.empty(B * T, dtype=torch.float32, device=dev),
@@ -518,9 +569,8 @@ def main():
         # merge_aligned_files.py:17-25), on its own stream so it overlaps later steps
         buf = seg_ring[g % 3]
         if pipelined:
-            plan.flush(comm.cuda_stream)   # the backtracks run on the plan's own stream: comm waits for every one enqueued so far
-        else:
-            comm.wait_stream(stream)
+            plan.flush(comm.cuda_stream)   # the backtracks run on the plan's own stream: comm waits for every one still in flight
+        comm.wait_stream(stream)           # ... and, either way, for what the caller's stream holds (fills; serial: everything)
         with torch.cuda.stream(comm):
             if rehearsal:   # gloo has no all_gather_into_tensor for device tensors
                 parts = [torch.empty_like(buf) for _ in range(world)]
@@ -536,6 +586,7 @@ def main():
         sg = seg_of(i)
         if do_gather and i % G == 0 and i >= 3 * G:
             stream.wait_stream(comm)   # the gather that last read this group buffer (group i/G - 3) has finished
+        d_lpz, d_lab, d_ub = d_in[i % NIN]   # a different input set every step: the emissions come from HBM
         plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(),
                         o["cp"].data_ptr(), None, sg[0].data_ptr(), sg[1].data_ptr(),
                         sg[2].data_ptr(), o["te"].data_ptr(), o["status"].data_ptr(),
@@ -545,11 +596,11 @@ def main():
                 gather(i // G)
 
     def drain():
-        if pipelined:
-            plan.flush(stream.cuda_stream)
-        if do_gather:
+        if do_gather:   # (first: the gathers order themselves behind the backtracks still in flight)
             for g in range(n_gathered[0], (n_calls[0] + G - 1) // G):   # groups not yet on their way (the last may be partial)
                 gather(g)
+        if pipelined:
+            plan.flush(stream.cuda_stream)
         if comm is not None:
             stream.wait_stream(comm)
 
@@ -591,25 +642,41 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fill_ms, bt_ms = plan.get_timings(n_timed)
+    # per-step samples from the events themselves: fill start of one recorded run to fill start of the next, / stride.
+    # The wall-clock figure of a short region also pays the one backtrack nothing overlaps (the last); the median of
+    # these does not, and a 20-step run gives the same number as a 1000-step one.
+    step_ev = plan.get_step_intervals(n_timed) / stride if n_timed >= 2 else np.zeros(0)
 
-    # ---- parity gate on the timed inputs (a sample; the full sweep is tests/ -m gpu) -------
-    last = outs[(args.steps - 1) % NSETS]
-    d_status, d_fol, d_seg, d_cp = last["status"], last["fol"], seg_of(args.steps - 1), last["cp"]
-    status = d_status.cpu().numpy()
-    assert args.no_check or (status == 0).all(), "non-OK status in the benchmark batch"
+    # ---- parity gate on the timed inputs: `--check-segments` segments of EACH of the last two timed steps (two
+    # input sets, two output sets, two workspaces) against the oracle; every segment's status.  The full-size check of
+    # the schedule (every segment of several steps) is tests/test_hip_parity.py::test_headline_schedule_full_oracle_check.
     parity = None
-    if rank == 0 and not args.no_check:
-        from oracle import oracle_c
-        ocfg = oracle_c.make_config(index_duration=INDEX_DURATION, backtrack_from_max_t=int(args.from_max_t))
-        fol = d_fol.cpu().numpy().reshape(B, C)
-        seg = d_seg.cpu().numpy().reshape(3, B, U)
-        cp = d_cp.cpu().numpy().reshape(B, T)
-        for b in (0, B // 2, B - 1):
-            o = oracle_c.get_segments(lpz[b], gt[b], ub[b], ocfg)
-            assert np.array_equal(fol[b], o["frame_of_label"]), f"segment {b}: frame indices differ from oracle"
-            assert np.array_equal(cp[b].astype(np.float64), o["char_probs"])
-            assert np.allclose(seg[2][b], o["seg_score"], rtol=0, atol=1e-4)
-        parity = "3 segments == oracle (frames bit-exact, scores<=1e-4)"
+    n_checked = 0
+    for back in (1, 2):
+        i = args.steps - back
+        if i < 0:
+            continue
+        o = outs[i % NSETS]
+        status = o["status"].cpu().numpy()
+        assert args.no_check or (status == 0).all(), "non-OK status in the benchmark batch"
+        if rank == 0 and not args.no_check and args.check_segments > 0:
+            from oracle import oracle_c
+            ocfg = oracle_c.make_config(index_duration=INDEX_DURATION, backtrack_from_max_t=int(args.from_max_t))
+            h_lpz, h_gt, h_ub = host_sets[i % NIN]
+            fol = o["fol"].cpu().numpy().reshape(B, C)
+            seg = seg_of(i).cpu().numpy().reshape(3, B, U)
+            cp = o["cp"].cpu().numpy().reshape(B, T)
+            te = o["te"].cpu().numpy()
+            for b in sorted(set(np.linspace(0, B - 1, min(B, args.check_segments)).astype(int).tolist())):
+                r = oracle_c.get_segments(h_lpz[b], h_gt[b], h_ub[b], ocfg)
+                assert te[b] == r["t_end"], f"step {i} segment {b}: end frame differs from oracle"
+                assert np.array_equal(fol[b], r["frame_of_label"]), f"step {i} segment {b}: frame indices differ from oracle"
+                assert np.array_equal(cp[b].astype(np.float64), r["char_probs"]), f"step {i} segment {b}: char_probs differ"
+                assert np.array_equal(seg[0][b], r["seg_start"]) and np.array_equal(seg[1][b], r["seg_end"])
+                assert np.allclose(seg[2][b], r["seg_score"], rtol=0, atol=1e-4)
+                n_checked += 1
+    if n_checked:
+        parity = f"{n_checked} segments of the last two timed steps == oracle (frames, char_probs bit-exact; scores<=1e-4)"
 
     if rank == 0:
         frames_total = world * B * T * args.steps
@@ -620,19 +687,29 @@ def main():
             "value": value, "unit": "audio-hours/s", "frames_per_s": fps,
             "n_gpus": world, **dist_info(dist, rehearsal), "steps": args.steps, "warmup": args.warmup,
             "spinup": {"steps": args.spinup_steps, "note": "untimed, before the warm-up steps: clock ramp from idle"},
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_events": ({"median": float(np.median(step_ev)), "mean": float(np.mean(step_ev)),
+                                    "p10": float(np.percentile(step_ev, 10)), "p90": float(np.percentile(step_ev, 90)),
+                                    "samples": int(len(step_ev)),
+                                    "note": f"fill start to fill start of consecutive HIP-event-bracketed launches / {stride}"}
+                                   if len(step_ev) else None),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: synthetic DP-only, %d segments x %d frames x "
                                    "vocab %d per GPU, C=%d label columns, %d utterances/segment"
                                    % (B, T, V, C, U),
                        "segments_per_gpu": B, "frames": T, "vocab": V, "label_columns": C,
+                       "input_sets": NIN, "input_bytes_resident": int(NIN * B * T * V * 4),
                        "cols_per_lane": info["cols_per_lane"], "waves_per_segment": info["waves_per_seg"],
                        "parallelism": f"segment-sharded x{world}", "parity": parity,
                        "gather": (f"RCCL all-gather of (start, end, score), one per {G} steps" if do_gather else None),
                        "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
             "roofline": roofline_entry(fill_ms, bt_ms, dt / args.steps * 1e3, stride,
                                        fill_bytes=B * (4 * T * V + T * C // 8), step_bytes=info["algorithmic_bytes"],
-                                       default_workload=(B, T, V, U, n) == (512, 3000, 32, 22, 28)),
+                                       default_workload=(B, T, V, U, n) == (512, 3000, 32, 22, 28), input_sets=NIN,
+                                       rows=T - 1, cols_per_lane=info["cols_per_lane"], serial=args.serial,
+                                       tiles_per_simd=-(-min(2, -(-B // 256)) * info["waves_per_seg"] // 4),
+                                       emission_bytes=B * T * V * 4),
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

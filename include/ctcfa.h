@@ -153,6 +153,10 @@ int ctcfa_plan_run_device(ctcfa_plan* plan, const float* d_lpz, const int32_t* d
  * enters `stream`.  Outputs of a call are complete on `stream` only after
  * ctcfa_plan_flush(plan, stream), which makes `stream` wait for every outstanding backtrack;
  * give consecutive calls different output buffers.  Same arguments as ctcfa_plan_run_device.
+ * ctcfa_plan_flush may be given ANY stream (the fill stream, a copy stream, a collective's stream): it
+ * orders that stream behind the outstanding backtracks and nothing else -- the plan keeps its own
+ * record of which workspace is still being read, so a flush on another stream never lets a later fill
+ * overwrite a workspace early.  It does NOT make `stream` wait for fills still queued elsewhere.
   * Where not a single backtrack workgroup finds room on a CU beside the plan's fill workgroups (LDS, registers:
  * vocabularies of 193+ entries, ...), the entry keeps its contract but runs the two kernels one after the other in
  * the caller's stream: side by side they would only slow each other down.
@@ -169,10 +173,14 @@ int ctcfa_plan_flush(ctcfa_plan* plan, void* stream);
  * set_timing_stride(k): record only every k-th run (an event record is a queue packet between
  * two kernels; k > 1 samples the run durations at a fraction of that cost).  Default 1.
  * get_timings(n, ...): durations [ms] of the last n RECORDED runs, oldest first; synchronises
- * on those runs' end events.  fill_ms / backtrack_ms: float[n], either may be NULL. */
+ * on those runs' end events.  fill_ms / backtrack_ms: float[n], either may be NULL.
+ * get_step_intervals(n, ms): float[n - 1], the time from the start of the fill of one recorded run to the start of
+ * the fill of the next recorded run, over the last n recorded runs (stride k: k steps of a back-to-back schedule) --
+ * per-step samples of a pipelined loop that a short wall-clock region cannot give (its last backtrack is not overlapped). */
 int ctcfa_plan_set_timing(ctcfa_plan* plan, int slots);
 int ctcfa_plan_set_timing_stride(ctcfa_plan* plan, int stride);
 int ctcfa_plan_get_timings(ctcfa_plan* plan, int n, float* fill_ms, float* backtrack_ms);
+int ctcfa_plan_get_step_intervals(ctcfa_plan* plan, int n, float* interval_ms);
 
 /*
  * Host-buffer convenience entry: same computation with HOST pointers; uploads,

@@ -24,7 +24,7 @@ EXPORTS = (
     "ctcfa_version", "ctcfa_status_string", "ctcfa_engine_create", "ctcfa_engine_destroy",
     "ctcfa_last_error", "ctcfa_default_params", "ctcfa_plan_create", "ctcfa_plan_destroy",
     "ctcfa_plan_get_info", "ctcfa_plan_run_device", "ctcfa_plan_run_pipelined", "ctcfa_plan_flush",
-    "ctcfa_plan_get_timings",
+    "ctcfa_plan_get_timings", "ctcfa_plan_get_step_intervals",
     "ctcfa_plan_set_timing", "ctcfa_plan_set_timing_stride", "ctcfa_align_batch", "ctcfa_align_batch_resident",
     "ctcfa_align_batch_shared", "ctcfa_plan_create_shared", "ctcfa_plan_get_sharing", "ctcfa_align_batch_spans",
     "ctcfa_build_flags", "ctcfa_max_label_columns",
@@ -108,6 +108,7 @@ def load():
     lib.ctcfa_plan_flush.argtypes = [vp, vp]
     lib.ctcfa_plan_get_timings.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]
+    lib.ctcfa_plan_get_step_intervals.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     lib.ctcfa_plan_set_timing.argtypes = [vp, ctypes.c_int]
     lib.ctcfa_plan_set_timing_stride.argtypes = [vp, ctypes.c_int]
     lib.ctcfa_align_batch.argtypes = [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
@@ -373,6 +374,12 @@ class Plan:
         b = (ctypes.c_float * n)()
         self._eng._check(self._lib.ctcfa_plan_get_timings(self._h, int(n), a, b), "ctcfa_plan_get_timings")
         return np.array(a[:], np.float64), np.array(b[:], np.float64)
+
+    def get_step_intervals(self, n):
+        """-> ms[n - 1]: fill start of one recorded run to fill start of the next, over the last n recorded runs."""
+        a = (ctypes.c_float * (n - 1))()
+        self._eng._check(self._lib.ctcfa_plan_get_step_intervals(self._h, int(n), a), "ctcfa_plan_get_step_intervals")
+        return np.array(a[:], np.float64)
 
     def run_device(self, d_lpz, d_labels, d_utt_begin, d_fol, d_char_prob, d_state, d_seg_start,
                    d_seg_end, d_seg_score, d_t_end, d_status, stream=None, pipelined=False):

@@ -240,13 +240,29 @@ ctcfa::FillRoles tile_roles(int K, int W, int NS, int nprod) {
         r.nwaves = W + nprod;
         for (int i = 0; i < r.nwaves; ++i) order[i] = i;
     }
+    // Issue priorities (s_setprio): the later half of a segment's tiles one above the earlier half, the producers below
+    // both and above the previous batch's striders.  CTCFA_TILE_PRIOS="p0,p1,.." / CTCFA_PROD_PRIO=p
+    // (tuning): per-tile priorities, the last one repeated.
+    int tile_prio[16], prod_prio = CTCFA_PRODUCER_PRIO;
+    for (int w = 0; w < 16; ++w) tile_prio[w] = CTCFA_TILE_PRIO_BASE + (w >= (W + 1) / 2 ? 1 : 0);
+    if (const char* e = std::getenv("CTCFA_TILE_PRIOS")) {
+        int last = tile_prio[0], w = 0;
+        for (const char* c = e; w < 16; ++w) {
+            if (*c) { last = std::atoi(c); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+            tile_prio[w] = last;
+        }
+    }
+    if (const char* e = std::getenv("CTCFA_PROD_PRIO")) prod_prio = std::atoi(e);
+    auto prio = [](int p) { return std::max(0, std::min(3, p)); };
     for (int i = 0; i < r.nwaves; ++i) r.wave[i] = {ctcfa::kRoleIdle, 0, 0};
-    for (int w = 0; w < W; ++w) r.wave[order[w]] = {ctcfa::kRoleTile, (int8_t)w, (int16_t)(w * U - XW)};
+    for (int w = 0; w < W; ++w)
+        r.wave[order[w]] = {ctcfa::role_with_prio(ctcfa::kRoleTile, prio(tile_prio[w])), (int8_t)w, (int16_t)(w * U - XW)};
+    const int8_t prole = ctcfa::role_with_prio(ctcfa::kRoleProducer, prio(prod_prio));
     if (padded8) {   // producers: second wave of SIMD pairs 2 and 3
-        r.wave[5] = {ctcfa::kRoleProducer, 0, 0};
-        if (nprod == 2) r.wave[7] = {ctcfa::kRoleProducer, 1, 0};
+        r.wave[5] = {prole, 0, 0};
+        if (nprod == 2) r.wave[7] = {prole, 1, 0};
     } else {
-        for (int p = 0; p < nprod; ++p) r.wave[order[W + p]] = {ctcfa::kRoleProducer, (int8_t)p, 0};
+        for (int p = 0; p < nprod; ++p) r.wave[order[W + p]] = {prole, (int8_t)p, 0};
     }
     return r;
 }
@@ -418,7 +434,7 @@ int ctcfa_build_flags(void) {
     f |= CTCFA_BUILD_ONE_PITCH;
 #endif
 #if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_PEEK_LEAD != 3 || \
-    CTCFA_NBR_SLEEP != 1 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
+    CTCFA_NBR_SLEEP != 1 || CTCFA_TWO_PROD32 != 0 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
     f |= CTCFA_BUILD_RETUNED;
 #endif
     return f;
@@ -497,7 +513,7 @@ int ctcfa_max_label_columns(const ctcfa_engine* eng, int32_t vocab) {
     if (!eng || vocab <= 0) return 0;
     const bool gather = vocab > kMaxStagedVocab;
     const int VP = gather ? 128 : vocab_pitch(vocab);
-    const int nprod = (!gather && (VP > 32 || vocab < 32)) ? 2 : 1;
+    const int nprod = (!gather && (VP > 32 || vocab < 32 || CTCFA_TWO_PROD32)) ? 2 : 1;
     return label_column_limit(eng->lds_limit, VP, nprod, gather);
 }
 
@@ -543,7 +559,11 @@ hipError_t scratch_get(ctcfa_engine* eng, int slot, void** p, size_t bytes) {
         hipError_t e = hipMalloc(&sl.p, cap);
         if (e != hipSuccess) return e;
         e = hipMemset(sl.p, 0, cap);   // (the workspace's error word must not start out as some future run's number)
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            (void)hipFree(sl.p);   // (cap is still 0: the next call would otherwise allocate over this pointer)
+            sl.p = nullptr;
+            return e;
+        }
         sl.cap = cap;
     }
     *p = sl.p;
@@ -618,7 +638,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->gather = gather;
     // Every vocabulary but the 32-entry one (whose rows a single wave moves with four wide loads per block) takes
     // two producer waves, each staging half the rows of every block: one alone cannot keep six tiles fed.
-    const int nprod = (!gather && (pl->VP > 32 || vocab < 32)) ? 2 : 1;
+    const int nprod = (!gather && (pl->VP > 32 || vocab < 32 || CTCFA_TWO_PROD32)) ? 2 : 1;
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.
@@ -1151,9 +1171,11 @@ int ctcfa_plan_run_device(ctcfa_plan* pl, const float* d_lpz, const int32_t* d_l
     GUARD_DEVICE(eng);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
     // a pipelined run may still be reading workspace 0 on the side stream
+    // (bt_pending stays set: the wait orders THIS stream only; a later pipelined run on another stream still has to see it)
     if (pl->bt_pending[0]) {
-        HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[0], 0));
-        pl->bt_pending[0] = false;
+        if (hipEventQuery(pl->bt_done_ev[0]) == hipSuccess) pl->bt_pending[0] = false;   // finished: nothing to order
+        else HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[0], 0));
+        (void)hipGetLastError();   // (a "not ready" from the query is no error)
     }
     const bool timed = pl->ev_slots && (pl->run_counter++ % pl->ev_stride == 0);
     hipEvent_t* ev = timed ? &pl->ev[(size_t)(pl->ev_runs % pl->ev_slots) * 4] : nullptr;
@@ -1221,11 +1243,15 @@ int ctcfa_plan_flush(ctcfa_plan* pl, void* stream) {
     ctcfa_engine* eng = pl->eng;
     GUARD_DEVICE(eng);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = the default (null) stream
+    // `st` (any stream: the caller's, a copy or a collective stream) waits for every backtrack still in flight.
+    // The workspaces stay marked as in use: the wait orders `st` only, not the stream the next fills are enqueued on,
+    // so the host-side check of ctcfa_plan_run_pipelined (event query / synchronise) must still see them.
     for (int q = 0; q < kWorkspaces; ++q)
         if (pl->bt_pending[q]) {
-            HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
-            pl->bt_pending[q] = false;
+            if (hipEventQuery(pl->bt_done_ev[q]) == hipSuccess) pl->bt_pending[q] = false;   // finished: nothing to order
+            else HIP_TRY(eng, hipStreamWaitEvent(st, pl->bt_done_ev[q], 0));
         }
+    (void)hipGetLastError();   // (a "not ready" from a query is no error)
     return CTCFA_OK;
 }
 
@@ -1242,6 +1268,22 @@ int ctcfa_plan_get_timings(ctcfa_plan* pl, int n, float* fill_ms, float* backtra
         HIP_TRY(eng, hipEventElapsedTime(&b, ev[2], ev[3]));
         if (fill_ms) fill_ms[i] = a;
         if (backtrack_ms) backtrack_ms[i] = b;
+    }
+    return CTCFA_OK;
+}
+
+int ctcfa_plan_get_step_intervals(ctcfa_plan* pl, int n, float* interval_ms) {
+    // time from the start of the fill of one RECORDED run to the start of the fill of the next recorded run (n - 1
+    // values for the last n recorded runs): with the timing stride s that is s steps of a back-to-back schedule
+    if (!pl || !interval_ms || n < 2 || !pl->ev_slots || n > pl->ev_slots || n > pl->ev_runs) return CTCFA_ERR_INVALID;
+    ctcfa_engine* eng = pl->eng;
+    GUARD_DEVICE(eng);
+    for (int i = 0; i + 1 < n; ++i) {
+        const int64_t run = pl->ev_runs - n + i;
+        hipEvent_t* e0 = &pl->ev[(size_t)(run % pl->ev_slots) * 4];
+        hipEvent_t* e1 = &pl->ev[(size_t)((run + 1) % pl->ev_slots) * 4];
+        HIP_TRY(eng, hipEventSynchronize(e1[0]));
+        HIP_TRY(eng, hipEventElapsedTime(&interval_ms[i], e0[0], e1[0]));
     }
     return CTCFA_OK;
 }

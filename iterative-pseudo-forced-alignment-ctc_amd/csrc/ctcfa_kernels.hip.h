@@ -56,6 +56,9 @@
 #ifndef CTCFA_VGPR_CAP
 #define CTCFA_VGPR_CAP 1
 #endif
+#ifndef CTCFA_TWO_PROD32
+#define CTCFA_TWO_PROD32 0   // tuning: two producer waves for the 32-entry vocabulary too (each stages every other group of 8 rows)
+#endif
 #ifndef CTCFA_ABL
 #define CTCFA_ABL 0   // tuning builds only (results are WRONG for > 0): parts of the group hand-over left out, to price them
 #endif
@@ -130,10 +133,17 @@ constexpr int kWatchMaxK = CTCFA_WATCH_MAX_K;        // widest tile the watch va
 // tile are its HALO: copies of the last HL*K columns of the tile to its left.
 enum : int8_t { kRoleIdle = 0, kRoleProducer = 1, kRoleTile = 2 };
 struct WaveRole {
-    int8_t role;
+    int8_t role;     // low nibble: kRole*; high nibble: the wave's issue priority (s_setprio 0..3), set by the host's role table
     int8_t stage;    // tile index (tiles), or the share of the rows a producer stages
     int16_t cbase;   // padded column of lane 0, k = 0 (tile 0: negative, its halo is left padding)
 };
+__host__ __device__ constexpr int8_t role_with_prio(int role, int prio) { return (int8_t)(role | (prio << 4)); }
+__device__ __forceinline__ void set_wave_prio(int p) {   // (s_setprio takes an immediate)
+    if (p <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
 struct FillRoles {
     int32_t nwaves;   // waves per workgroup (blockDim.x / 64)
     int32_t nstages;  // compute tiles W
@@ -170,6 +180,24 @@ constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a los
 #endif
 
 using lds_vint = volatile __attribute__((address_space(3))) int;   // counters in LDS
+
+// CTCFA_STAMP=4 (tuning builds): a TIMELINE -- every tile leaves an s_memtime stamp at the end of every 16-row group, the
+// producers one per block they publish and one per wait for ring space, for the first kTraceWgs workgroups; plus the
+// wave's HW_ID (which SIMD / CU it runs on).  tools/trace4.py turns them into who-waits-for-whom tables.
+constexpr int kTraceWgs = 16;
+constexpr int kTraceSlots = 256;                 // u64 per (workgroup, wave)
+constexpr int kTraceBase = 4 * 64 * 16 * 8;      // u64 offset into the stamp buffer (behind what CTCFA_STAMP <= 3 writes)
+#if defined(CTCFA_STAMP) && CTCFA_STAMP == 4
+#define CTCFA_TRACE(wave_slot, slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < ctcfa::kTraceWgs && (slot) < ctcfa::kTraceSlots) \
+    (reinterpret_cast<unsigned long long*>(lastcol) + ctcfa::kTraceBase + ((int)blockIdx.x * 16 + (wave_slot)) * ctcfa::kTraceSlots)[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CTCFA_TRACE_HWID(wave_slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < ctcfa::kTraceWgs) { unsigned hw_, xcc_; \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); \
+    (reinterpret_cast<unsigned long long*>(lastcol) + ctcfa::kTraceBase + ((int)blockIdx.x * 16 + (wave_slot)) * ctcfa::kTraceSlots)[ctcfa::kTraceSlots - 1] = \
+        ((unsigned long long)xcc_ << 32) | hw_; } } while (0)
+#else
+#define CTCFA_TRACE(wave_slot, slot) do { } while (0)
+#define CTCFA_TRACE_HWID(wave_slot) do { } while (0)
+#endif
 
 __host__ __device__ constexpr int halo_lanes(int K) { return (kHaloRows + K - 1) / K; }
 
@@ -242,7 +270,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WaveRole my = roles->wave[wave_id];
+    WaveRole my = roles->wave[wave_id];
+    const int my_prio = __builtin_amdgcn_readfirstlane((my.role >> 4) & 3);
+    my.role = (int8_t)(my.role & 15);
     const int W = roles->nstages;         // compute tiles
     const int NS = roles->nslots;         // emission ring slots
     constexpr int XR = kExchangeRing;     // exchange ring: groups a tile can be ahead of its right neighbour (>= 2 NS; a power of two: g % XR is an AND)
@@ -294,7 +324,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         // ahead of the LDS writes (registers), the writes up to NS - 1 blocks ahead of the tiles.
         // Little work (~5 % of a SIMD's issue slots) but everybody's critical path: without priority the
         // tiles on its SIMD starve it and the whole workgroup runs at the producer's pace.
-        __builtin_amdgcn_s_setprio(CTCFA_PRODUCER_PRIO);
+        set_wave_prio(my_prio);
         const int part = my.stage;  // which share of the rows (nprod == 2), and which staged[] counter
         int fix_mode = 0;           // how two producers split a block: 0 every other row, 2 every other group of four rows, 3 halves
         constexpr int PASSES = kRows * VP / 64;
@@ -305,10 +335,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         unsigned long long pst_space = 0, pst_t0 = __builtin_amdgcn_s_memtime(), pst_w0 = 0, pst_write = 0;
         int pst_n = 0;
 #endif
+        CTCFA_TRACE_HWID(14 + my.stage);
         auto wait_space = [&](int jb) {   // every tile is done with the block that slot jb % NS still holds
 #ifdef CTCFA_STAMP
             pst_w0 = __builtin_amdgcn_s_memtime();
 #endif
+            CTCFA_TRACE(14 + my.stage, 120 + jb);   // (producer rows: [jb] published, [120 + jb] began to wait for space)
             if (jb < NS) return;
             const int need = kGroups * (jb - NS + 1);
             const int idx = lane < W ? lane : 0;
@@ -340,6 +372,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
             asm volatile("" ::: "memory");  // data and posflag first, then the counter (LDS executes a wave's operations in order)
             if (lane == 0) flags[16 + part] = jb + 1;
+            CTCFA_TRACE(14 + part, jb);
 #ifdef CTCFA_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             pst_write += __builtin_amdgcn_s_memtime() - pst_w0;
@@ -397,7 +430,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // 64 entries: two producers, each takes every other pass (four rows) of a block -- four passes and
             // two register sets per wave, like the single producer of the 32-entry case (one producer with
             // one set had a block's HBM latency in front of every block: 207 us)
-            constexpr int PSTEP = (VP == 64) ? 2 : 1;   // (two producers for the 32-entry case too: measured in round 3, 143.8 against 143.1 us)
+            constexpr int PSTEP = (VP == 64 || (VP == 32 && CTCFA_TWO_PROD32)) ? 2 : 1;   // (two producers for the 32-entry case too: measured in round 3, 143.8 against 143.1 us)
             constexpr int NP = NPB / PSTEP;
             const int lr = lane / LPR;
             const int lv = (lane % LPR) * 4;
@@ -741,8 +774,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // half first 148, producer above the tiles 165-170, "a tile that had to wait steps back" 155).  Round 3: tiles
     // 3 / 2, producers 1 -- one above the striders of the previous batch's backtrack (priority 0), which otherwise
     // share the producers' level: 0.1559 -> 0.1542 ms per pipelined step, the fill alone unchanged.
-    if (w >= (W + 1) / 2) __builtin_amdgcn_s_setprio(CTCFA_TILE_PRIO_BASE + 1);
-    else __builtin_amdgcn_s_setprio(CTCFA_TILE_PRIO_BASE);
+    set_wave_prio(my_prio);   // (the role table: ctcfa.hip tile_roles -- later half CTCFA_TILE_PRIO_BASE + 1, earlier half CTCFA_TILE_PRIO_BASE)
 
     // Dead zone: column c cannot reach the end cell's column C-1 from rows t > T-C+c, so the
     // backtrack never visits those cells and they feed only other dead cells (in this tile or, through
@@ -793,6 +825,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
 #define CTCFA_STAMP_BEGIN() do { } while (0)
 #define CTCFA_STAMP_END(acc, cnt) do { } while (0)
 #endif
+    CTCFA_TRACE_HWID(w);
     int cur_slot = 0;  // slot whose offset is folded into gaddr[]
     int jslot = 0;     // j % NS of the block loop below
 
@@ -849,7 +882,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         }
 #pragma unroll
         for (int i = 0; i < kRows; ++i) {
-#if defined(CTCFA_STAMP) && CTCFA_STAMP >= 3   // where inside a block the cycles go: a stamp every 8 rows of block 40
+#if defined(CTCFA_STAMP) && CTCFA_STAMP == 3   // where inside a block the cycles go: a stamp every 8 rows of block 40
             if (i % 8 == 0 && (j == CTCFA_STAMP_BLOCK || j == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
                 (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[i / 8] = __builtin_amdgcn_s_memtime();
 #endif
@@ -945,6 +978,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             }
             if (i % kHaloRows == kHaloRows - 1) {   // group end: my last columns for the tile to my right, then the counter
+                CTCFA_TRACE(w, g);
                 if constexpr (K == 1) {
                     // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data.
                     // One-column tiles only: with more columns per lane 64 lanes' worth of LDS writes cost more than
@@ -970,7 +1004,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
             }
         }
-#if defined(CTCFA_STAMP) && CTCFA_STAMP >= 3
+#if defined(CTCFA_STAMP) && CTCFA_STAMP == 3
         if ((j == CTCFA_STAMP_BLOCK || j == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
             (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[4] = __builtin_amdgcn_s_memtime();
 #endif

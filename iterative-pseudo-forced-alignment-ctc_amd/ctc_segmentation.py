@@ -239,10 +239,13 @@ def _segment_errors(lpz_list, labels, utt_begin_list):
     errors, minus_one = [None] * len(lpz_list), [False] * len(lpz_list)
     if not lpz_list:
         return errors, minus_one
-    V = int(lpz_list[0].shape[1])
+    # the launch's vocabulary width: the one most well-formed segments agree on (ties: the earliest) -- a malformed or
+    # odd first segment is that segment's error, not the launch's
+    widths = [int(l.shape[1]) for l in lpz_list if getattr(l, "ndim", 0) == 2]
+    V = max(dict.fromkeys(widths), key=widths.count) if widths else 0
     for b, (l, g) in enumerate(zip(lpz_list, labels)):
-        if l.ndim != 2 or int(l.shape[1]) != V:
-            errors[b] = ValueError(f"segment {b}: emissions must be [T, {V}] like the first segment's, got {tuple(l.shape)}")
+        if getattr(l, "ndim", 0) != 2 or int(l.shape[1]) != V:
+            errors[b] = ValueError(f"segment {b}: emissions must be [T, {V}] like the launch's other segments, got {tuple(getattr(l, 'shape', ()))}")
         elif len(g) < 2 or g[0] != -1:
             errors[b] = ValueError(f"segment {b}: ground truth must start with -1 and hold at least one more label")
         else:

@@ -137,6 +137,11 @@ def test_inputs_numpy_would_refuse_are_refused_on_the_host(pkg):
                                            [np.array([1, 4]), np.array([1, 3]), np.array([1, 4])])
     assert errors[0] is None and isinstance(errors[1], IndexError) and errors[2] is None
     assert minus_one == [False, False, True]
+    # a malformed or odd FIRST segment is that segment's error too: the launch's width is the one most segments agree on
+    errors, _ = cs._segment_errors([np.zeros(7, np.float32), lpz, lpz], [good, good, good], None)
+    assert isinstance(errors[0], ValueError) and errors[1] is None and errors[2] is None
+    errors, _ = cs._segment_errors([np.zeros((5, 9), np.float32), lpz, lpz], [good, good, good], None)
+    assert isinstance(errors[0], ValueError) and errors[1] is None and errors[2] is None
 
 
 def test_every_task_keeps_its_own_timing_config(pkg):
