@@ -98,7 +98,7 @@ const char* ctcfa_status_string(int status);
  * (tools/build_variant.sh) and must never serve results: ablated builds leave out parts of the
  * fill kernel's hand-over (WRONG results, timing only), stamp builds write cycle counts into output
  * buffers.  The Python binding refuses to load such a library unless CTCFA_ALLOW_TUNING_BUILD=1. */
-#define CTCFA_BUILD_ABLATED   1   /* -DCTCFA_ABL > 0 */
+#define CTCFA_BUILD_ABLATED   1   /* -DCTCFA_ABL != 0 */
 #define CTCFA_BUILD_STAMPS    2   /* -DCTCFA_STAMP / -DCTCFA_BT_STAMP */
 #define CTCFA_BUILD_ONE_PITCH 4   /* -DCTCFA_DEV_VP32_ONLY: vocabularies up to 32 entries only */
 #define CTCFA_BUILD_RETUNED   8   /* any other tuning macro off its default */

@@ -29,7 +29,7 @@ struct ScratchSlot {
     void* p = nullptr;
     size_t cap = 0;
 };
-enum { kSlotLpz, kSlotIn, kSlotOut, kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kSlotCompact, kNumSlots };
+enum { kSlotLpz, kSlotIn, kSlotOut, kSlotSegs, kSlotRoles, kSlotBits, kSlotLastcol, kSlotCompact, kSlotWinTable, kSlotWinOffs, kSlotWinList, kNumSlots };
 
 struct ctcfa_engine {
     int device = -1;
@@ -424,7 +424,7 @@ int ctcfa_version(void) { return CTCFA_VERSION; }
 
 int ctcfa_build_flags(void) {
     int f = 0;
-#if CTCFA_ABL > 0
+#if CTCFA_ABL != 0
     f |= CTCFA_BUILD_ABLATED;
 #endif
 #if defined(CTCFA_STAMP) || defined(CTCFA_BT_STAMP)
@@ -433,7 +433,7 @@ int ctcfa_build_flags(void) {
 #ifdef CTCFA_DEV_VP32_ONLY
     f |= CTCFA_BUILD_ONE_PITCH;
 #endif
-#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_PEEK_LEAD != 3 || \
+#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || \
     CTCFA_NBR_SLEEP != 1 || CTCFA_TWO_PROD32 != 0 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
     f |= CTCFA_BUILD_RETUNED;
 #endif
@@ -526,6 +526,9 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
         plan->d_bits[0] = nullptr;
         plan->d_lastcol[0] = nullptr;
         plan->d_watch = nullptr;
+        plan->d_win_list = nullptr;
+        plan->d_win_table = nullptr;
+        plan->d_win_offs = nullptr;
     }
     if (plan->d_watch) (void)hipFree(plan->d_watch);
     if (plan->d_segs) (void)hipFree(plan->d_segs);
@@ -966,11 +969,20 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                                                 : reinterpret_cast<const void*>(select_strider(pl->VP)),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
     if (!pl->win_list.empty()) {
-        PLAN_TRY(hipMalloc(&pl->d_win_list, sizeof(int32_t) * pl->win_list.size()));
+        if (use_scratch) {
+            // (a plan that lives for one host-buffer call: the windowed kernel's table -- 47 MB for ONE 9 500-frame window,
+            // 12 GB for 256 -- comes from the engine's grow-only scratch like the other workspaces; a hipMalloc / hipFree
+            // pair of that size per call cost up to 600 ms, profiles/r03_windowed.txt.  The kernel initialises its table.)
+            PLAN_TRY(scratch_get(eng, kSlotWinList, reinterpret_cast<void**>(&pl->d_win_list), sizeof(int32_t) * pl->win_list.size()));
+            PLAN_TRY(scratch_get(eng, kSlotWinTable, reinterpret_cast<void**>(&pl->d_win_table), sizeof(float) * (size_t)pl->win_table_floats));
+            PLAN_TRY(scratch_get(eng, kSlotWinOffs, reinterpret_cast<void**>(&pl->d_win_offs), sizeof(int32_t) * (size_t)pl->win_cols));
+        } else {
+            PLAN_TRY(hipMalloc(&pl->d_win_list, sizeof(int32_t) * pl->win_list.size()));
+            PLAN_TRY(hipMalloc(&pl->d_win_table, sizeof(float) * (size_t)pl->win_table_floats));
+            PLAN_TRY(hipMalloc(&pl->d_win_offs, sizeof(int32_t) * (size_t)pl->win_cols));
+        }
         PLAN_TRY(hipMemcpy(pl->d_win_list, pl->win_list.data(), sizeof(int32_t) * pl->win_list.size(),
                            hipMemcpyHostToDevice));
-        PLAN_TRY(hipMalloc(&pl->d_win_table, sizeof(float) * (size_t)pl->win_table_floats));
-        PLAN_TRY(hipMalloc(&pl->d_win_offs, sizeof(int32_t) * (size_t)pl->win_cols));
         if (pl->lds_win > 48 * 1024)
             PLAN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ctcfa::windowed_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_win));
@@ -1076,7 +1088,12 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
                           ((pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0) |
                               ((pl->prm.flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) ? 2 : 0),
                           (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch,
-                          reinterpret_cast<int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)), (int)pl->last_run[ws]);
+#if defined(CTCFA_STAMP) && CTCFA_STAMP == 4   // the timeline of tools/trace4.py: behind the caller's char_prob buffer (which the tool makes long enough)
+                          reinterpret_cast<int32_t*>(a.d_char_prob + (pl->total_T + 1) / 2 * 2),
+#else
+                          reinterpret_cast<int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
+#endif
+                          (int)pl->last_run[ws]);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }

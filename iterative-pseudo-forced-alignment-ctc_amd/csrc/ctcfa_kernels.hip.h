@@ -60,7 +60,15 @@
 #define CTCFA_TWO_PROD32 0   // tuning: two producer waves for the 32-entry vocabulary too (each stages every other group of 8 rows)
 #endif
 #ifndef CTCFA_ABL
-#define CTCFA_ABL 0   // tuning builds only (results are WRONG for > 0): parts of the group hand-over left out, to price them
+#define CTCFA_ABL 0   // tuning builds only (results are WRONG for != 0), a bit mask of what is left out, to price it: 1 the group hand-over
+                      // (exchange rows, counters, waits for the neighbour), 2 the waits between tiles and producer (staged / ring space),
+                      // 4 the trace-word and last-column stores, 8 the producer's work (it leaves at once; needs 2)
+#endif
+#ifndef CTCFA_PROD_PACE
+#define CTCFA_PROD_PACE 0   // s_sleep argument (x 64 clocks) between two LDS stores of a producer in the steady state (0: back to back)
+#endif
+#ifndef CTCFA_BODY_BLOCKS
+#define CTCFA_BODY_BLOCKS 2   // 32-row blocks per body of the tile loop where the ring allows it (1: one block per body, as up to round 3)
 #endif
 #ifndef CTCFA_PF
 #define CTCFA_PF 2  // rows of LDS prefetch distance in the fill kernel
@@ -159,16 +167,12 @@ constexpr int kGroups = kRows / kHaloRows;
 #ifndef CTCFA_POLL_LEAD
 #define CTCFA_POLL_LEAD 4
 #endif
-#ifndef CTCFA_PEEK_LEAD
-#define CTCFA_PEEK_LEAD 3
-#endif
 #ifndef CTCFA_NBR_SLEEP
 #define CTCFA_NBR_SLEEP 1
 #endif
-constexpr int kPollLead = CTCFA_POLL_LEAD;   // a tile asks for its neighbour's group this many rows before it needs it
-constexpr int kPeekLead = CTCFA_PEEK_LEAD;   // ... and reads the counter this many rows before it looks at the value
+constexpr int kPollLead = CTCFA_POLL_LEAD;   // a tile reads its neighbour's counter and exchange row this many rows before the group's end (where it looks at them)
 constexpr int kExchangeRing = 8;    // group slots of a tile's exchange ring (ring slots NS <= 4, two groups per block)
-constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, pad
+constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, always-done [19], pad
 constexpr int kBigCount = 0x3fffffff;
 constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a lost counter must not hang the GPU
 #ifdef CTCFA_DEBUG_SPIN
@@ -185,14 +189,16 @@ using lds_vint = volatile __attribute__((address_space(3))) int;   // counters i
 // producers one per block they publish and one per wait for ring space, for the first kTraceWgs workgroups; plus the
 // wave's HW_ID (which SIMD / CU it runs on).  tools/trace4.py turns them into who-waits-for-whom tables.
 constexpr int kTraceWgs = 16;
-constexpr int kTraceSlots = 256;                 // u64 per (workgroup, wave)
-constexpr int kTraceBase = 4 * 64 * 16 * 8;      // u64 offset into the stamp buffer (behind what CTCFA_STAMP <= 3 writes)
+constexpr int kTraceSlots = 1024;                // u64 per (workgroup, wave): [g] group end, [256 + g] at the neighbour poll, [512 + g] past it, [768 + j] block start
+// (the timeline lives BEHIND the caller's char_prob buffer, 16 bytes past the word `fill_err` points at in stamp builds:
+// inside the buffer the owner tiles' last-column scores would overwrite it)
+#define CTCFA_TRACE_PTR (reinterpret_cast<unsigned long long*>(fill_err) + 2)
 #if defined(CTCFA_STAMP) && CTCFA_STAMP == 4
 #define CTCFA_TRACE(wave_slot, slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < ctcfa::kTraceWgs && (slot) < ctcfa::kTraceSlots) \
-    (reinterpret_cast<unsigned long long*>(lastcol) + ctcfa::kTraceBase + ((int)blockIdx.x * 16 + (wave_slot)) * ctcfa::kTraceSlots)[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+    (CTCFA_TRACE_PTR + ((int)blockIdx.x * 16 + (wave_slot)) * ctcfa::kTraceSlots)[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CTCFA_TRACE_HWID(wave_slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < ctcfa::kTraceWgs) { unsigned hw_, xcc_; \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); \
-    (reinterpret_cast<unsigned long long*>(lastcol) + ctcfa::kTraceBase + ((int)blockIdx.x * 16 + (wave_slot)) * ctcfa::kTraceSlots)[ctcfa::kTraceSlots - 1] = \
+    (CTCFA_TRACE_PTR + ((int)blockIdx.x * 16 + (wave_slot)) * ctcfa::kTraceSlots)[ctcfa::kTraceSlots - 1] = \
         ((unsigned long long)xcc_ << 32) | hw_; } } while (0)
 #else
 #define CTCFA_TRACE(wave_slot, slot) do { } while (0)
@@ -312,7 +318,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     {
         float* xch = reinterpret_cast<float*>(smem + xch_base);
         for (int i = tid; i < W * XR * XW; i += blockDim.x) xch[i] = kProbMax;
-        if (tid < kFlagInts) flags[tid] = (tid == 17 && roles->nprod < 2) ? kBigCount : 0;
+        if (tid < kFlagInts) flags[tid] = ((tid == 17 && roles->nprod < 2) || tid == 19) ? kBigCount : 0;   // (19: the counter tile 0 "waits" on)
         if (tid < wn) reinterpret_cast<int64_t*>(smem + wtab_base)[tid] = seg_watch[tid].frm_off;
     }
     lds_barrier();  // the only workgroup barrier: everything after it is counter-paced
@@ -336,7 +342,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         int pst_n = 0;
 #endif
         CTCFA_TRACE_HWID(14 + my.stage);
+        if (CTCFA_ABL & 8) return;
         auto wait_space = [&](int jb) {   // every tile is done with the block that slot jb % NS still holds
+            if (CTCFA_ABL & 2) return;
 #ifdef CTCFA_STAMP
             pst_w0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -453,6 +461,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const uint32_t spc = (lv == 0) ? slot + static_cast<uint32_t>((lr * PITCH + VP) * 8)
                                                : sink_base + static_cast<uint32_t>(lane * 8);
                 const int t0 = jb * kRows + 1 + lr;
+                const bool paced = jb >= 2 * NS;   // (the first rings' worth goes out as fast as it can: the tiles are waiting for it)
 #pragma unroll
                 for (int pp = 0; pp < NP; ++pp) {
                     const int p = pp * PSTEP + (PSTEP == 2 ? part : 0);
@@ -467,13 +476,41 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const float2 sp = make_float2(-__builtin_inff(),
                                                   (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
                     unsigned char* q = smem + ent + p * (RPP * PITCH * 8);
+                    // Round 4 (the ablations of profiles/r04_fill_ablations.txt): these few stores are what the producer costs the
+                    // tiles -- 17 us of the 140 -- not its loads or its vector work.  A store moves its address and data registers to
+                    // the LDS over a path the wave shares with every other wave of its SIMD pair (2 cycles a dword: 13 per
+                    // ds_write_b128), and a block's twelve in a row hold that path longer than the tiles' two rows of prefetched
+                    // gathers last: every tile of the pair stood still once per block.  In the steady state the producer is a ring
+                    // ahead and has a block's time for its stores: it sleeps between them (s_sleep 4 = 256 clocks), so that each is
+                    // a hiccup the tiles' prefetch absorbs; and the start-column entry, a constant under
+                    // preamble_transition_cost_zero, is written once for the whole ring instead of once per row.
+                    if (CTCFA_ABL & 32) { lo = make_float4(v.x, v.x, v.y, v.y); hi = make_float4(v.z, v.z, v.w, v.w); }   // (tuning: no vector work on the values)
+                    if (CTCFA_ABL & 16) { asm volatile("" :: "v"(lo.x), "v"(lo.y), "v"(lo.z), "v"(lo.w), "v"(hi.x), "v"(hi.y), "v"(hi.z), "v"(hi.w), "v"(sp.y)); continue; }   // (tuning: no LDS stores)
+                    if (CTCFA_ABL & 64) {   // (tuning: the same bytes as four 8-byte stores instead of two 16-byte ones)
+                        *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
+                        *reinterpret_cast<float2*>(q + 8) = make_float2(lo.z, lo.w);
+                        *reinterpret_cast<float2*>(q + 16) = make_float2(hi.x, hi.y);
+                        *reinterpret_cast<float2*>(q + 24) = make_float2(hi.z, hi.w);
+                    } else {
                     *reinterpret_cast<float4*>(q) = lo;
+#if CTCFA_PROD_PACE > 0
+                    if (paced) __builtin_amdgcn_s_sleep(CTCFA_PROD_PACE);
+#endif
                     *reinterpret_cast<float4*>(q + 16) = hi;
+#if CTCFA_PROD_PACE > 0
+                    if (paced) __builtin_amdgcn_s_sleep(CTCFA_PROD_PACE);
+#endif
+                    }
                     // sink offsets stay inside the 1 KB sink: p * RPP * PITCH * 8 would not
+                    if (!preamble && !(CTCFA_ABL & 128))   // (under preamble_transition_cost_zero: written once, below)
                     *reinterpret_cast<float2*>(smem + spc + ((lv == 0) ? p * (RPP * PITCH * 8) : 0)) = sp;
                 }
             };
             if constexpr (PSTEP == 2) fix_mode = 2;
+            if (preamble && part == 0)   // start-column entry (e = -inf, stay step 0) of every row of the ring, once (before this wave's first publish: LDS order)
+                for (int idx = lane; idx < NS * kRows; idx += 64)
+                    *reinterpret_cast<float2*>(smem + static_cast<uint32_t>((idx / kRows) * SLOT_BYTES + (idx % kRows) * (PITCH * 8) + VP * 8)) =
+                        make_float2(-__builtin_inff(), 0.0f);
             {   // two register sets: loads run a block ahead of the LDS writes
                 // (a third set -- loads two blocks ahead -- measured no faster, and does not fit the
                 // 64-register budget of the narrow tiles)
@@ -767,6 +804,11 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const uint32_t xin_addr = xch_base + static_cast<uint32_t>(((w > 0 ? w - 1 : 0) * XR * XW + (lane < HL ? lane : HL - 1) * K) * 4);
     const uint32_t xout_addr = xch_base + static_cast<uint32_t>((w * XR * XW + (lane >= 64 - HL ? lane - (64 - HL) : 0) * K) * 4);
     const bool publishes = lane >= 64 - HL;
+    // K <= 2: at a group's end EVERY lane stores (no branch, no exec-mask juggling): the lanes that publish nothing write into
+    // the sink (their own 4 K bytes of it per exchange slot: lane * 4 K + 8 slots * 4 XW <= 1 KB), and every lane but the last
+    // stores its copy of the counter there too (the last 256 bytes of the sink)
+    const uint32_t xw_addr = (K > 2 || publishes) ? xout_addr : sink_base + static_cast<uint32_t>(lane * K * 4);
+    const uint32_t cnt_out_addr = (lane == 63) ? flag_base + static_cast<uint32_t>(w * 4) : sink_base + 1024u + static_cast<uint32_t>(lane * 4);
 
     // Tiles of one SIMD compete for issue slots by priority, then age: the later-dispatched waves
     // would always lose.  A tile is only ever waited for by its right neighbour, so the left ones go first.
@@ -814,7 +856,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         return __builtin_amdgcn_readfirstlane(a < b ? a : b);
     };
     int staged_seen = 0;
-    int peek = 0, peek_sa = 0, peek_sb = 0;   // counter values on their way from LDS
+    int peek_sa = 0, peek_sb = 0;   // counter values on their way from LDS
 #ifdef CTCFA_STAMP   // tuning builds: where a tile's cycles go (tools/stamps2.py reads them from the lastcol workspace)
     unsigned long long st_nbr = 0, st_staged = 0, st_t0 = __builtin_amdgcn_s_memtime();
     int st_nbr_n = 0, st_staged_n = 0;
@@ -840,17 +882,47 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             if (t >= 1 && t < T) lastcol[off + t] = v;
         }
     };
-    // one 32-row block; OWNER 1: this tile holds the last label column and also publishes its scores;
-    // OWNER 2 (shared fill): it holds watch columns, each in some lane at some k
-    auto block_impl = [&](int j, auto owner_tag, auto start_tag) {
+    // One BODY of the tile loop = NB consecutive 32-row blocks (NB = 2 where the ring has an even number of slots and the
+    // body starts in an even one: the two slots are contiguous in LDS, every row of the 64 is `VGPR + immediate`).  Round 4:
+    // what lies between two bodies -- loop latch, staged-counter check, slot arithmetic, dispatch on the tile's kind, the LDS
+    // prefetch queue running dry and filling up again -- cost a tile 600..800 cycles per 32 rows (tools/trace4.py: a fifth of
+    // a block's time), and the group hand-over 25 instructions; now one boundary per 64 rows and 10 instructions per group:
+    //   * 4 rows before a group's end: the neighbour's counter, THEN its exchange row of this group (LDS executes a wave's
+    //     operations in order; the writer stores data, then counter) -- both reads issued back to back, nothing looked at yet;
+    //   * at the group's end: my own columns and my counter go out -- every lane stores (K <= 2: the lanes that publish
+    //     nothing write into the sink: no branch, no exec-mask juggling); then the counter read above is compared with the
+    //     group number: if the neighbour had not finished the group when the counter was read (it normally is 4+ rows
+    //     ahead), the tile spins on the counter and reads the row again;
+    //   * tile 0 reads a counter that is always "done" (flags[19]) and its own ring: no `w > 0` branches in the row loop.
+    // OWNER 1: this tile holds the last label column and also publishes its scores; OWNER 2 (shared fill): it holds watch
+    // columns, each in some lane at some k.
+    lds_vint* cnt_in = flags + (w > 0 ? w - 1 : 19);
+    // The owner of the last label column is the tile everybody ends up waiting for (through the ring: trace4), and what it does
+    // more than the others sat on its critical path: the row's score went to the LDS ring right behind the v_max3 that makes
+    // it (the wave stood still until the result was there, then for the store's register transfer: +18 cycles a row), and at
+    // every block's end the 32 scores were read back and stored to HBM with a full LDS round trip in between.  Round 4: the
+    // score of row i is stored while row i + 1 is computed (`own_pend`), and block j's scores leave for HBM in the middle of
+    // block j + 1 (`own_copy`), from the ring half nobody writes to then.
+    float own_pend = 0.0f;     // OWNER 1: last-column score of the row before, not yet in the ring
+    bool own_have = false;     // ... there is one
+    bool own_copy = false;     // OWNER 1: the block before this one is complete in the ring and not yet in `lastcol`
+    auto block_impl = [&](int j, auto owner_tag, auto start_tag, auto nb_tag) {
         constexpr int OWNER = decltype(owner_tag)::value;
         constexpr bool START = decltype(start_tag)::value;   // E_ALONE: some column of this tile is the start column or padding left of it
+        constexpr int NB = decltype(nb_tag)::value;
+        constexpr int ROWS = NB * kRows;
+        CTCFA_TRACE(w, 768 + j);
         const int slot = jslot;   // j % NS, kept by the block loop (NS is 3 or 4: a division otherwise)
         const uint32_t delta = static_cast<uint32_t>((slot - cur_slot) * SLOT_BYTES);
         cur_slot = slot;
 #pragma unroll
         for (int k = 0; k < K; ++k) gaddr[k] += delta;
         if constexpr (E_ALONE) xaddr += delta;
+        // exchange slots of this body's groups: (2j + q) % XR, q = 0 .. 2 NB - 1 (no wrap inside a body: XR is a multiple of 2 NB
+        // and a two-block body starts at an even block)
+        const int g0 = j * kGroups;
+        const uint32_t xoff = static_cast<uint32_t>((g0 & (XR - 1)) * XW * 4);
+        const uint32_t xin_cur = xin_addr + xoff, xw_cur = xw_addr + xoff;
         // Owner tiles publish the score of their watched column after every row: ring entry q of the half (j & 1)
         // holds table row 32 j + q, so row i goes to entry i + 1 and the block's last row to entry 0 of the OTHER
         // half.  One ds_write_b32 per row straight from the register (every lane stores; the lanes that watch
@@ -859,12 +931,19 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         uint32_t out_addr = sink_base + static_cast<uint32_t>(lane * 4);
         if (OWNER == 1 && lane == lstar) out_addr = lcring_base;
         if (OWNER == 2 && myslot >= 0) out_addr = wring_base + static_cast<uint32_t>(myslot * 64 * 4);
-        const uint32_t half_cur = static_cast<uint32_t>((j & 1) * kRows * 4), half_nxt = static_cast<uint32_t>(((j + 1) & 1) * kRows * 4);
-        if constexpr (OWNER != 0) {
+        const uint32_t half_even = static_cast<uint32_t>((j & 1) * kRows * 4), half_odd = static_cast<uint32_t>(((j + 1) & 1) * kRows * 4);
+        if constexpr (OWNER == 1) {
+            // entry 0 of this block's half: the last row of the block before -- still pending from the body before, or -1e9 in
+            // every label column if that block was skipped (or there is none)
+            *reinterpret_cast<float*>(smem + out_addr + half_even) = own_have ? own_pend : kProbMax;
+            own_have = false;
+        } else if constexpr (OWNER == 2) {
             if (!ring_has_row0)   // the block before was skipped (or there is none): its last row is -1e9 in every label column
-                *reinterpret_cast<float*>(smem + out_addr + half_cur) = kProbMax;
+                *reinterpret_cast<float*>(smem + out_addr + half_even) = kProbMax;
             ring_has_row0 = true;
         }
+        float own_val = 0.0f;   // OWNER 1: last-column scores of the block before, on their way from the ring to HBM
+        uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase;   // trace words of block j, lane 0 (then + Cpad): wave-uniform
 
         // software pipeline: operands of row i+PF are requested while row i is computed
         constexpr int PF = CTCFA_PF;
@@ -880,13 +959,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 else emq[d][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + d * ROW_BYTES);
             }
         }
+        int cnt_seen = 0;
 #pragma unroll
-        for (int i = 0; i < kRows; ++i) {
+        for (int i = 0; i < ROWS; ++i) {
+            const int jj = i / kRows, ii = i % kRows, q = i / kHaloRows;   // block of the body, row of the block, group of the body
 #if defined(CTCFA_STAMP) && CTCFA_STAMP == 3   // where inside a block the cycles go: a stamp every 8 rows of block 40
-            if (i % 8 == 0 && (j == CTCFA_STAMP_BLOCK || j == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
-                (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[i / 8] = __builtin_amdgcn_s_memtime();
+            if (ii % 8 == 0 && (j + jj == CTCFA_STAMP_BLOCK || j + jj == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
+                (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j + jj - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[ii / 8] = __builtin_amdgcn_s_memtime();
 #endif
-            if (i % kHaloRows == 0 && CTCFA_ABL < 2) {   // group start: the neighbour's columns replace what went wrong in my halo
+            if (i % kHaloRows == 0 && !(CTCFA_ABL & 1)) {   // group start: the neighbour's columns replace what went wrong in my halo
 #pragma unroll
                 for (int k = 0; k < K; ++k) prev[k] = is_halo ? hx[k] : prev[k];
             }
@@ -898,7 +979,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     const float e = eq[i % PF][k];
                     em[k] = make_float2(e, max3f((START && startlike[k]) ? xr.y : xr.x, e, kProbMax));
                 }
-                if (i + PF < kRows) {
+                if (i + PF < ROWS) {
                     xq[i % PF] = *reinterpret_cast<const float2*>(smem + xaddr + (i + PF) * ROW_BYTES);
 #pragma unroll
                     for (int k = 0; k < K; ++k)
@@ -907,10 +988,24 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             } else {
 #pragma unroll
                 for (int k = 0; k < K; ++k) em[k] = emq[i % PF][k];
-                if (i + PF < kRows) {
+                if (i + PF < ROWS) {
 #pragma unroll
                     for (int k = 0; k < K; ++k)
                         emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * ROW_BYTES);
+                }
+            }
+            if constexpr (OWNER == 1 && !(CTCFA_ABL & 4) && !(CTCFA_ABL & 256)) {   // (tuning, 256: the owner's stores alone left out)
+                if (i > 0) {   // the score of row i - 1 (a register nobody waits for any more) goes to the ring: entry ii' + 1 of its block's half, the block's last row to entry 0 of the other
+                    const int pj = (i - 1) / kRows, pi = (i - 1) % kRows;
+                    const uint32_t hc = (pj & 1) ? half_odd : half_even, hn = (pj & 1) ? half_even : half_odd;
+                    *reinterpret_cast<float*>(smem + out_addr + (pi + 1 < kRows ? hc + static_cast<uint32_t>((pi + 1) * 4) : hn)) = own_pend;
+                }
+                // the block before this one: from the ring half nobody writes to now, to HBM -- read here, stored four rows on
+                if (ii == 8 && (jj > 0 || own_copy))
+                    own_val = *reinterpret_cast<const float*>(smem + lcring_base + (((j + jj - 1) & 1) * kRows + (lane & 31)) * 4);
+                if (ii == 12 && (jj > 0 || own_copy)) {
+                    const int t = (j + jj - 1) * kRows + lane;
+                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = own_val;
                 }
             }
             // lane 0 has no left neighbour: it is a halo lane (its first column goes wrong at once, by
@@ -932,13 +1027,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
                 prev[k] = nw;
             }
-            if constexpr (OWNER != 0) {
+            if constexpr (OWNER == 1) own_pend = prev[K - 1];
+            if constexpr (OWNER == 2) {
                 float pv = prev[K - 1];
-                if constexpr (OWNER == 2) {
 #pragma unroll
-                    for (int k = 0; k < K - 1; ++k) pv = (ksel == k) ? prev[k] : pv;
-                }
-                *reinterpret_cast<float*>(smem + out_addr + (i + 1 < kRows ? half_cur + static_cast<uint32_t>((i + 1) * 4) : half_nxt)) = pv;
+                for (int k = 0; k < K - 1; ++k) pv = (ksel == k) ? prev[k] : pv;
+                const uint32_t hc = (jj & 1) ? half_odd : half_even, hn = (jj & 1) ? half_even : half_odd;
+                *reinterpret_cast<float*>(smem + out_addr + (ii + 1 < kRows ? hc + static_cast<uint32_t>((ii + 1) * 4) : hn)) = pv;
             }
             // Pin this row's decisions here (empty asm = opaque use, no instruction): dec[] is
             // consumed at the end of the block, and LLVM otherwise sinks the residual math of
@@ -948,94 +1043,115 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if constexpr (CK) asm volatile("" : "+v"(prev[k]));  // (keeps the rows apart for the scheduler)
                 else asm volatile("" : "+v"(dec[k]));
             }
-            const int g = j * kGroups + i / kHaloRows;   // the group this row belongs to
-            if (i % kHaloRows == kHaloRows - 1 - kPollLead - kPeekLead) {
-                // the counters are read a few rows before they are looked at: no LDS round trip in the way
-                if (w > 0 && CTCFA_ABL < 1) peek = flags[w - 1];
-                if (i / kHaloRows == kGroups - 1) {   // (for the next block: no wait at its start)
+            if (i % kHaloRows == kHaloRows - 1 - kPollLead) {
+                // my neighbour's counter, then its columns at the end of this group (for my next one): read now, looked at at
+                // the group's end -- no LDS round trip in the way
+                CTCFA_TRACE(w, 256 + g0 + q);
+                if (!(CTCFA_ABL & 1)) {
+                cnt_seen = *cnt_in;
+                asm volatile("" ::: "memory");
+                const float* xr = reinterpret_cast<const float*>(smem + xin_cur + static_cast<uint32_t>(q * XW * 4));
+#pragma unroll
+                for (int k = 0; k < K; ++k) hx[k] = xr[k];
+                }
+                if (i == ROWS - 1 - kPollLead) {   // (for the next body: no wait at its start)
                     peek_sa = flags[16];
                     peek_sb = flags[17];
                 }
             }
-            if (i % kHaloRows == kHaloRows - 1 - kPollLead && CTCFA_ABL < 2) {
-                if (w > 0) {   // my neighbour's columns at the end of this group, for my next one
-                    if (CTCFA_ABL < 1 && __builtin_expect(__builtin_amdgcn_readfirstlane(peek) < g + 1, 0)) {   // (normally it is 4+ rows ahead)
-                        CTCFA_STAMP_BEGIN();
-                        int f, spins = 0;
-                        do {
-#if CTCFA_NBR_SLEEP > 0
-                            __builtin_amdgcn_s_sleep(CTCFA_NBR_SLEEP);
-#endif
-                            f = __builtin_amdgcn_readfirstlane(flags[w - 1]);
-                            if (++spins > kSpinCap) { CTCFA_SPIN_DIAG("tile-nbr", w, g, f); break; }
-                        } while (f < g + 1);
-                        CTCFA_STAMP_END(st_nbr, st_nbr_n);
-                    }
-                    asm volatile("" ::: "memory");
-                    const float* xr = reinterpret_cast<const float*>(smem + xin_addr + static_cast<uint32_t>((g % XR) * XW * 4));
-#pragma unroll
-                    for (int k = 0; k < K; ++k) hx[k] = xr[k];
-                }
-            }
             if (i % kHaloRows == kHaloRows - 1) {   // group end: my last columns for the tile to my right, then the counter
+                const int g = g0 + q;
                 CTCFA_TRACE(w, g);
-                if constexpr (K == 1) {
-                    // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data.
-                    // One-column tiles only: with more columns per lane 64 lanes' worth of LDS writes cost more than
-                    // the branch (K = 3, 4096 segments: +9 %), with one column the chain of 14 tiles gains 8 %.
-                    if (CTCFA_ABL < 4 || i == kRows - 1) {
-                        float* xw = reinterpret_cast<float*>(smem + (publishes ? xout_addr + static_cast<uint32_t>((g % XR) * XW * 4)
-                                                                               : sink_base + static_cast<uint32_t>(lane * 16)));
-                        if (CTCFA_ABL < 3) {
+                if (CTCFA_ABL & 1) {
+                    if (ii == kRows - 1 && lane == 63) flags[w] = g + 1;   // (the producer still wants to know)
+                } else
+                if constexpr (K <= 2) {
+                    // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data, no exec juggling.
+                    // Narrow tiles only: with more columns per lane 64 lanes' worth of LDS writes cost more than the branch
+                    // (K = 3, 4096 segments: +9 %).
+                    float* xw = reinterpret_cast<float*>(smem + xw_cur + static_cast<uint32_t>(q * XW * 4));
 #pragma unroll
-                            for (int k = 0; k < K; ++k) xw[k] = prev[k];
-                        }
-                        asm volatile("" ::: "memory");
-                        if (lane == 63) flags[w] = g + 1;
-                    }
-                } else if (publishes && (CTCFA_ABL < 4 || i == kRows - 1)) {
-                    float* xw = reinterpret_cast<float*>(smem + xout_addr + static_cast<uint32_t>((g % XR) * XW * 4));
-                    if (CTCFA_ABL < 3) {
+                    for (int k = 0; k < K; ++k) xw[k] = prev[k];
+                    asm volatile("" ::: "memory");
+                    *((lds_vint*)(smem + cnt_out_addr)) = g + 1;
+                } else if (publishes) {
+                    float* xw = reinterpret_cast<float*>(smem + xw_cur + static_cast<uint32_t>(q * XW * 4));
 #pragma unroll
-                        for (int k = 0; k < K; ++k) xw[k] = prev[k];
-                    }
+                    for (int k = 0; k < K; ++k) xw[k] = prev[k];
                     asm volatile("" ::: "memory");
                     if (lane == 63) flags[w] = g + 1;
                 }
+                if (!(CTCFA_ABL & 1) && __builtin_expect(__builtin_amdgcn_readfirstlane(cnt_seen) < g + 1, 0)) {   // (normally the neighbour is 4+ rows ahead)
+                    CTCFA_STAMP_BEGIN();
+                    int f, spins = 0;
+                    do {
+#if CTCFA_NBR_SLEEP > 0
+                        __builtin_amdgcn_s_sleep(CTCFA_NBR_SLEEP);
+#endif
+                        f = __builtin_amdgcn_readfirstlane(*cnt_in);
+                        if (++spins > kSpinCap) { CTCFA_SPIN_DIAG("tile-nbr", w, g, f); break; }
+                    } while (f < g + 1);
+                    CTCFA_STAMP_END(st_nbr, st_nbr_n);
+                    CTCFA_TRACE(w, 512 + g);
+                    asm volatile("" ::: "memory");
+                    const float* xr = reinterpret_cast<const float*>(smem + xin_cur + static_cast<uint32_t>(q * XW * 4));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) hx[k] = xr[k];
+                    // (used here, so that the wait for it sits on this path: where the two paths meet again the compiler would
+                    // otherwise wait for EVERY outstanding LDS read -- the prefetch queue drained at each group's start)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) asm volatile("" : "+v"(hx[k]));
+                }
+                if (ii == kRows - 1) {   // end of block j + jj
+                    // trace words of this block (fire and forget: this wave never waits on vmcnt); halo lanes hold
+                    // copies that have gone wrong by now
+#if defined(CTCFA_STAMP) && CTCFA_STAMP == 3
+                    if ((j + jj == CTCFA_STAMP_BLOCK || j + jj == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
+                        (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j + jj - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[4] = __builtin_amdgcn_s_memtime();
+#endif
+                    if (lane >= HL && !(CTCFA_ABL & 4)) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) CTCFA_TRACE_STORE(bp + lane * K + k, CK ? __float_as_uint(prev[k]) : dec[k]);
+                    }
+                    bp += Cpad;
+                    if constexpr (OWNER == 2) watch_out(j + jj, true);
+                }
             }
         }
-#if defined(CTCFA_STAMP) && CTCFA_STAMP == 3
-        if ((j == CTCFA_STAMP_BLOCK || j == CTCFA_STAMP_BLOCK + 1) && lane == 0 && blockIdx.x < 64)
-            (reinterpret_cast<unsigned long long*>(lastcol) + (1 + j - CTCFA_STAMP_BLOCK) * 64 * 16 * 8 + (blockIdx.x * 16 + w) * 8)[4] = __builtin_amdgcn_s_memtime();
-#endif
-        // trace words of this block (fire and forget: this wave never waits on vmcnt); halo lanes hold
-        // copies that have gone wrong by now
-        if (lane >= HL) {
-            uint32_t* bp = bits + sd.bits_off + (int64_t)j * Cpad + cbase + lane * K;
-#pragma unroll
-            for (int k = 0; k < K; ++k) CTCFA_TRACE_STORE(bp + k, CK ? __float_as_uint(prev[k]) : dec[k]);
+        if constexpr (OWNER == 1) {
+            own_have = true;    // (own_pend: the body's last row)
+            own_copy = true;    // the body's last block is complete in the ring but for its last row, which belongs to the next block's entry 0
         }
-        if constexpr (OWNER == 1) {  // last-column scores for the end-cell argmax: rows 32j .. 32j+31 are complete
-            const int t = j * kRows + lane;
-            if (lane < kRows && t >= 1 && t < T)
-                seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((j & 1) * kRows + lane) * 4);
-        }
-        if constexpr (OWNER == 2) watch_out(j, true);
     };
 
     // (only tile 0 holds the start column: the other tiles' code carries no select for it -- one vector instruction per
     // cell less on the tiles that are waited for)
     const bool tile_has_start = E_ALONE && cbase - shift <= 0;
-    auto block = [&](int j, auto owner_tag) {
+    auto block = [&](int j, auto owner_tag, auto nb_tag) {
         if constexpr (E_ALONE) {
-            if (tile_has_start) block_impl(j, owner_tag, std::true_type{});
-            else block_impl(j, owner_tag, std::false_type{});
+            if (tile_has_start) block_impl(j, owner_tag, std::true_type{}, nb_tag);
+            else block_impl(j, owner_tag, std::false_type{}, nb_tag);
         } else {
-            block_impl(j, owner_tag, std::false_type{});
+            block_impl(j, owner_tag, std::false_type{}, nb_tag);
         }
     };
-    for (int j = 0; j <= jlast; ++j, jslot = (jslot + 1 == NS) ? 0 : jslot + 1) {
+    // two-block bodies: the (e, m) pair kernels (their loop overhead is what a narrow tile notices); a ring with an even
+    // number of slots, a body that starts in an even slot, both blocks staged already, both inside the tile's live range
+    constexpr bool kPairs = !E_ALONE && CTCFA_BODY_BLOCKS >= 2;
+    const bool ring_even = (NS & 1) == 0;
+    auto body = [&](int j, auto nb_tag) {
+        if constexpr (K <= kWatchMaxK) {
+            if (watch_tile) {
+                block(j, std::integral_constant<int, 2>{}, nb_tag);
+                return;
+            }
+        }
+        if (w == wstar && wn == 0) block(j, std::integral_constant<int, 1>{}, nb_tag);
+        else block(j, std::integral_constant<int, 0>{}, nb_tag);
+    };
+    for (int j = 0; j <= jlast;) {
         staged_seen = __builtin_amdgcn_readfirstlane(peek_sa < peek_sb ? peek_sa : peek_sb);
+        if (CTCFA_ABL & 2) staged_seen = j + 2;
         if (__builtin_expect(staged_seen <= j, 0)) {   // emissions of block j (normally seen staged while block j-1 was computed)
             CTCFA_STAMP_BEGIN();
             for (int spins = 0;; ++spins) {
@@ -1053,7 +1169,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     watch_out(j, false);
                 } else if (w == wstar) {
                     const int t = j * kRows + lane;
-                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;
+                    if (lane < kRows && t >= 1 && t < T) seg_lastcol[t] = kProbMax;   // (own_copy / own_have stay false: nothing computed yet)
                 }
                 if constexpr (CK) {  // the table row this block would have ended in
                     if (lane >= HL) {
@@ -1063,22 +1179,34 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     }
                 }
                 if (lane == 63) flags[w] = kGroups * (j + 1);   // (its exchange rows are still the initial -1e9)
+                ++j;
+                jslot = (jslot + 1 == NS) ? 0 : jslot + 1;
                 continue;
             }
             jfirst = 0;            // emissions are not log-probabilities: compute everything from here on
         }
-        if constexpr (K <= kWatchMaxK) {
-            if (watch_tile) {
-                block(j, std::integral_constant<int, 2>{});
-                continue;
-            }
+        int nb = 1;
+        if constexpr (kPairs) {
+            if (ring_even && (jslot & 1) == 0 && j + 1 <= jlast && staged_seen > j + 1) nb = 2;
         }
-        if (w == wstar && wn == 0) block(j, std::integral_constant<int, 1>{});
-        else block(j, std::integral_constant<int, 0>{});
+        if constexpr (kPairs) {
+            if (nb == 2) body(j, std::integral_constant<int, 2>{});
+            else body(j, std::integral_constant<int, 1>{});
+        } else {
+            body(j, std::integral_constant<int, 1>{});
+        }
+        j += nb;
+        jslot += nb;
+        if (jslot >= NS) jslot -= NS;
 #ifdef CTCFA_STAMP   // when the first two computed blocks ended: what a cold instruction cache costs a launch
         if (st_first[0] == 0) st_first[0] = __builtin_amdgcn_s_memtime() - st_t0;
         else if (st_first[1] == 0) st_first[1] = __builtin_amdgcn_s_memtime() - st_t0;
 #endif
+    }
+    if (own_copy) {   // the owner's last block: from the ring to HBM
+        const int t = jlast * kRows + lane;
+        if (lane < kRows && t >= 1 && t < T)
+            seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((jlast & 1) * kRows + lane) * 4);
     }
     if (lane == 63) flags[w] = kBigCount;   // done (end of the segment or dead zone): nobody waits for this tile again
 #ifdef CTCFA_STAMP

@@ -6,7 +6,7 @@ for K in $1; do
             "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU" \
             "SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS"; do
   rm -rf gpurun_out/pmcx
-  rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --spinup-steps 0 --cpu-sample 0 --no-check --serial --cols-per-lane $K $2 > gpurun_out/pmcx.log 2>&1 || { tail -5 gpurun_out/pmcx.log; continue; }
+  rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcx -- python3 bench.py --steps 4 --warmup 2 --spinup-steps 0 --cpu-sample 0 --no-check --serial --input-sets 2 --cols-per-lane $K $2 > gpurun_out/pmcx.log 2>&1 || { tail -5 gpurun_out/pmcx.log; continue; }
   python3 - "$K" <<'PY'
 import csv,glob,sys,collections
 f=glob.glob('gpurun_out/pmcx/*/*_counter_collection.csv')
