@@ -433,7 +433,7 @@ int ctcfa_build_flags(void) {
 #ifdef CTCFA_DEV_VP32_ONLY
     f |= CTCFA_BUILD_ONE_PITCH;
 #endif
-#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || \
+#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || CTCFA_MASKED_PUBLISH != 1 || CTCFA_OWNER_DEFER != 0 || CTCFA_LEAN_HANDOVER != 1 || \
     CTCFA_NBR_SLEEP != 1 || CTCFA_TWO_PROD32 != 0 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
     f |= CTCFA_BUILD_RETUNED;
 #endif
@@ -1471,9 +1471,18 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     unsigned char *d_in = nullptr, *d_out = nullptr;
     if (!d_lpz) AB_TRY(scratch_get(eng, kSlotLpz, reinterpret_cast<void**>(&d_lpz), n_lpz * sizeof(float)));
     AB_TRY(scratch_get(eng, kSlotIn, reinterpret_cast<void**>(&d_in), in_bytes));
-    AB_TRY(scratch_get(eng, kSlotOut, reinterpret_cast<void**>(&d_out), out_bytes));
     AB_TRY(pinned_get(&eng->h_in, &eng->h_in_cap, in_bytes));
     AB_TRY(pinned_get(&eng->h_out, &eng->h_out_cap, out_bytes));
+    // Small calls (a window of the anchor iteration: a few KB of results): the backtrack writes its results straight into
+    // the pinned result block -- posted writes over PCIe -- and the download, a copy packet of its own in the queue
+    // (~7 us between the last kernel and the host), goes away.  Only where the last kernel never reads its outputs back
+    // (the checkpoint-mode backtrack keeps its own copies in LDS; the decision-word one scores from frame_of_label in
+    // memory, the windowed and rescoring kernels read what the backtrack wrote).
+    static const bool no_direct = std::getenv("CTCFA_NO_DIRECT_OUT") != nullptr;
+    const bool direct_out = !no_direct && out_bytes <= (size_t)(96 << 10) && pl->ckpt && pl->win_list.empty() &&
+                            pl->prm.score_min_mean_over_L <= 128;
+    if (direct_out) AB_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out), eng->h_out, 0));
+    else AB_TRY(scratch_get(eng, kSlotOut, reinterpret_cast<void**>(&d_out), out_bytes));
     unsigned char* h = eng->h_in;
     std::memcpy(h + in_roles, &pl->roles, sizeof(ctcfa::FillRoles));
     std::memcpy(h + in_segs, pl->segs.data(), sizeof(SegDesc) * (size_t)batch);
@@ -1517,7 +1526,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     }
     lap(3);
     unsigned char* ho = eng->h_out;
-    AB_TRY(hipMemcpyAsync(ho, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    if (!direct_out) AB_TRY(hipMemcpyAsync(ho, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     lap(4);
     AB_TRY(hipStreamSynchronize(st));
     lap(5);

@@ -67,6 +67,20 @@
 #ifndef CTCFA_PROD_PACE
 #define CTCFA_PROD_PACE 0   // s_sleep argument (x 64 clocks) between two LDS stores of a producer in the steady state (0: back to back)
 #endif
+// Round 4's changes to the tile loop, each behind a switch (measured on one box, profiles/r04_fill_variants.txt: fill alone |
+// pipelined step, config 3: round 3 142.7 us | 0.1605 ms; lean hand-over alone 139.7 | 0.1592; + two-block bodies 135.6 | 0.1604;
+// + every lane publishing 135.7 | 0.1646; + the owner's stores deferred 137.3 | 0.1637 -- and for the 38-entry vocabulary every
+// one of them LOSES against round 3's loop, 171..175 us against 164): shipped = lean hand-over and two-block bodies for the
+// 32-entry pitch, round 3's loop for every other pitch.
+#ifndef CTCFA_LEAN_HANDOVER
+#define CTCFA_LEAN_HANDOVER 1    // 32-entry pitch: counter and exchange row read together 4 rows before a group's end, looked at at its end; 0 = rounds 2-3 everywhere
+#endif
+#ifndef CTCFA_MASKED_PUBLISH
+#define CTCFA_MASKED_PUBLISH 1   // 1 = two-column tiles store their exchange row under an exec mask (rounds 2-3); 0 = every lane stores (the rest into the sink)
+#endif
+#ifndef CTCFA_OWNER_DEFER
+#define CTCFA_OWNER_DEFER 0      // 1 = the owner tile stores a row's score one row later and copies a block's scores out in the middle of the next block
+#endif
 #ifndef CTCFA_BODY_BLOCKS
 #define CTCFA_BODY_BLOCKS 2   // 32-row blocks per body of the tile loop where the ring allows it (1: one block per body, as up to round 3)
 #endif
@@ -807,7 +821,9 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // K <= 2: at a group's end EVERY lane stores (no branch, no exec-mask juggling): the lanes that publish nothing write into
     // the sink (their own 4 K bytes of it per exchange slot: lane * 4 K + 8 slots * 4 XW <= 1 KB), and every lane but the last
     // stores its copy of the counter there too (the last 256 bytes of the sink)
-    const uint32_t xw_addr = (K > 2 || publishes) ? xout_addr : sink_base + static_cast<uint32_t>(lane * K * 4);
+    constexpr bool kLean = VP == 32 && CTCFA_LEAN_HANDOVER;   // (the other pitches: rounds 2-3's hand-over, below)
+    constexpr bool kAllLanesPublish = K == 1 || (K == 2 && !CTCFA_MASKED_PUBLISH);
+    const uint32_t xw_addr = (!kAllLanesPublish || publishes) ? xout_addr : sink_base + static_cast<uint32_t>(lane * K * 4);
     const uint32_t cnt_out_addr = (lane == 63) ? flag_base + static_cast<uint32_t>(w * 4) : sink_base + 1024u + static_cast<uint32_t>(lane * 4);
 
     // Tiles of one SIMD compete for issue slots by priority, then age: the later-dispatched waves
@@ -994,7 +1010,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         emq[i % PF][k] = *reinterpret_cast<const float2*>(smem + gaddr[k] + (i + PF) * ROW_BYTES);
                 }
             }
-            if constexpr (OWNER == 1 && !(CTCFA_ABL & 4) && !(CTCFA_ABL & 256)) {   // (tuning, 256: the owner's stores alone left out)
+            if constexpr (OWNER == 1 && CTCFA_OWNER_DEFER && !(CTCFA_ABL & 4) && !(CTCFA_ABL & 256)) {   // (tuning, 256: the owner's stores alone left out)
                 if (i > 0) {   // the score of row i - 1 (a register nobody waits for any more) goes to the ring: entry ii' + 1 of its block's half, the block's last row to entry 0 of the other
                     const int pj = (i - 1) / kRows, pi = (i - 1) % kRows;
                     const uint32_t hc = (pj & 1) ? half_odd : half_even, hn = (pj & 1) ? half_even : half_odd;
@@ -1027,7 +1043,15 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 }
                 prev[k] = nw;
             }
-            if constexpr (OWNER == 1) own_pend = prev[K - 1];
+            if constexpr (OWNER == 1) {
+                own_pend = prev[K - 1];
+#if !CTCFA_OWNER_DEFER
+                if (!(CTCFA_ABL & 4) && !(CTCFA_ABL & 256)) {   // (rounds 1-3: the score goes to the ring at once)
+                    const uint32_t hc = (jj & 1) ? half_odd : half_even, hn = (jj & 1) ? half_even : half_odd;
+                    *reinterpret_cast<float*>(smem + out_addr + (ii + 1 < kRows ? hc + static_cast<uint32_t>((ii + 1) * 4) : hn)) = own_pend;
+                }
+#endif
+            }
             if constexpr (OWNER == 2) {
                 float pv = prev[K - 1];
 #pragma unroll
@@ -1043,7 +1067,41 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if constexpr (CK) asm volatile("" : "+v"(prev[k]));  // (keeps the rows apart for the scheduler)
                 else asm volatile("" : "+v"(dec[k]));
             }
-            if (i % kHaloRows == kHaloRows - 1 - kPollLead) {
+            if constexpr (!kLean) {
+                // rounds 2-3's hand-over: the counter is read 7 rows before the group's end, looked at 4 rows before it (a spin
+                // if the neighbour is not there yet), and only then the exchange row is read
+                const int g = g0 + q;
+                if (i % kHaloRows == kHaloRows - 1 - kPollLead - 3) {
+                    if (w > 0 && !(CTCFA_ABL & 1)) cnt_seen = flags[w - 1];
+                    if (i == ROWS - 1 - kPollLead - 3) {   // (for the next body: no wait at its start)
+                        peek_sa = flags[16];
+                        peek_sb = flags[17];
+                    }
+                }
+                if (i % kHaloRows == kHaloRows - 1 - kPollLead && !(CTCFA_ABL & 1)) {
+                    if (w > 0) {   // my neighbour's columns at the end of this group, for my next one
+                        CTCFA_TRACE(w, 256 + g);
+                        if (__builtin_expect(__builtin_amdgcn_readfirstlane(cnt_seen) < g + 1, 0)) {   // (normally it is 4+ rows ahead)
+                            CTCFA_STAMP_BEGIN();
+                            int f, spins = 0;
+                            do {
+#if CTCFA_NBR_SLEEP > 0
+                                __builtin_amdgcn_s_sleep(CTCFA_NBR_SLEEP);
+#endif
+                                f = __builtin_amdgcn_readfirstlane(flags[w - 1]);
+                                if (++spins > kSpinCap) { CTCFA_SPIN_DIAG("tile-nbr", w, g, f); break; }
+                            } while (f < g + 1);
+                            CTCFA_STAMP_END(st_nbr, st_nbr_n);
+                            CTCFA_TRACE(w, 512 + g);
+                        }
+                        asm volatile("" ::: "memory");
+                        const float* xr = reinterpret_cast<const float*>(smem + xin_cur + static_cast<uint32_t>(q * XW * 4));
+#pragma unroll
+                        for (int k = 0; k < K; ++k) hx[k] = xr[k];
+                    }
+                }
+            }
+            if (kLean && i % kHaloRows == kHaloRows - 1 - kPollLead) {
                 // my neighbour's counter, then its columns at the end of this group (for my next one): read now, looked at at
                 // the group's end -- no LDS round trip in the way
                 CTCFA_TRACE(w, 256 + g0 + q);
@@ -1065,7 +1123,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if (CTCFA_ABL & 1) {
                     if (ii == kRows - 1 && lane == 63) flags[w] = g + 1;   // (the producer still wants to know)
                 } else
-                if constexpr (K <= 2) {
+                if constexpr (kAllLanesPublish) {
                     // every lane stores (the lanes that publish nothing: into the sink) -- no branch around the data, no exec juggling.
                     // Narrow tiles only: with more columns per lane 64 lanes' worth of LDS writes cost more than the branch
                     // (K = 3, 4096 segments: +9 %).
@@ -1081,7 +1139,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     asm volatile("" ::: "memory");
                     if (lane == 63) flags[w] = g + 1;
                 }
-                if (!(CTCFA_ABL & 1) && __builtin_expect(__builtin_amdgcn_readfirstlane(cnt_seen) < g + 1, 0)) {   // (normally the neighbour is 4+ rows ahead)
+                if (kLean && !(CTCFA_ABL & 1) && __builtin_expect(__builtin_amdgcn_readfirstlane(cnt_seen) < g + 1, 0)) {   // (normally the neighbour is 4+ rows ahead)
                     CTCFA_STAMP_BEGIN();
                     int f, spins = 0;
                     do {
@@ -1114,13 +1172,20 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         for (int k = 0; k < K; ++k) CTCFA_TRACE_STORE(bp + lane * K + k, CK ? __float_as_uint(prev[k]) : dec[k]);
                     }
                     bp += Cpad;
+#if !CTCFA_OWNER_DEFER
+                    if constexpr (OWNER == 1) {  // (rounds 1-3) last-column scores for the end-cell argmax: rows 32(j+jj) .. +31 are complete
+                        const int t = (j + jj) * kRows + lane;
+                        if (lane < kRows && t >= 1 && t < T)
+                            seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + (((j + jj) & 1) * kRows + lane) * 4);
+                    }
+#endif
                     if constexpr (OWNER == 2) watch_out(j + jj, true);
                 }
             }
         }
         if constexpr (OWNER == 1) {
             own_have = true;    // (own_pend: the body's last row)
-            own_copy = true;    // the body's last block is complete in the ring but for its last row, which belongs to the next block's entry 0
+            own_copy = CTCFA_OWNER_DEFER != 0;    // the body's last block is complete in the ring but for its last row, which belongs to the next block's entry 0
         }
     };
 
@@ -1137,7 +1202,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     };
     // two-block bodies: the (e, m) pair kernels (their loop overhead is what a narrow tile notices); a ring with an even
     // number of slots, a body that starts in an even slot, both blocks staged already, both inside the tile's live range
-    constexpr bool kPairs = !E_ALONE && CTCFA_BODY_BLOCKS >= 2;
+    constexpr bool kPairs = VP == 32 && CTCFA_BODY_BLOCKS >= 2;
     const bool ring_even = (NS & 1) == 0;
     auto body = [&](int j, auto nb_tag) {
         if constexpr (K <= kWatchMaxK) {

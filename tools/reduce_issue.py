@@ -31,7 +31,11 @@ valu = {
     "wave_valu_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
     # the vector ALUs of a SIMD: cycles some wave has a VALU instruction in flight / the SIMD's cycles in the launch.
     # SQ_BUSY_CYCLES is per shader engine (32 of them), SQ_ACTIVE_INST_VALU per wave -> normalise by the 1024 SIMDs.
-    "busy_frac": (c["SQ_ACTIVE_INST_VALU"] / 1024.0) / (c["SQ_BUSY_CYCLES"] / 32.0) if c.get("SQ_BUSY_CYCLES") else None,
+    # (SQ_ACTIVE_INST_VALU counts about one unit per instruction here, whatever its length: the figure is built from the
+    # instruction count and the measured issue cost of this kernel's mix instead -- 6 vector instructions of a K = 2 row take
+    # 16.1 cycles of a SIMD alone, profiles/r01_issue_rates.txt / r04_valu_rate2.txt: 2.68 cycles an instruction)
+    "busy_frac": (c["SQ_INSTS_VALU"] * 2.68 / 1024.0) / (c["SQ_BUSY_CYCLES"] / 32.0) if c.get("SQ_BUSY_CYCLES") else None,
+    "busy_frac_note": "vector instructions per launch x 2.68 cycles (this row loop's measured mix) / (1024 SIMDs x the launch's cycles, SQ_BUSY_CYCLES per shader engine)",
     "lds_busy_frac": (c["SQ_LDS_IDX_ACTIVE"] / 256.0) / (c["SQ_BUSY_CYCLES"] / 32.0) if c.get("SQ_BUSY_CYCLES") and c.get("SQ_LDS_IDX_ACTIVE") else None,
     "lds_conflict_cycles_per_inst": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"] if c.get("SQ_INSTS_LDS") else None,
     "kernel_us_under_profiler": sum(wall) / len(wall) if wall else None,
