@@ -433,7 +433,7 @@ int ctcfa_build_flags(void) {
 #ifdef CTCFA_DEV_VP32_ONLY
     f |= CTCFA_BUILD_ONE_PITCH;
 #endif
-#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || CTCFA_MASKED_PUBLISH != 1 || CTCFA_OWNER_DEFER != 0 || CTCFA_LEAN_HANDOVER != 1 || \
+#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || CTCFA_MASKED_PUBLISH != 1 || CTCFA_OWNER_DEFER != 0 || CTCFA_LEAN_HANDOVER != 1 || CTCFA_ADDTID_PRODUCER != 1 || \
     CTCFA_NBR_SLEEP != 1 || CTCFA_TWO_PROD32 != 0 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
     f |= CTCFA_BUILD_RETUNED;
 #endif
@@ -513,7 +513,7 @@ int ctcfa_max_label_columns(const ctcfa_engine* eng, int32_t vocab) {
     if (!eng || vocab <= 0) return 0;
     const bool gather = vocab > kMaxStagedVocab;
     const int VP = gather ? 128 : vocab_pitch(vocab);
-    const int nprod = (!gather && (VP > 32 || vocab < 32 || CTCFA_TWO_PROD32)) ? 2 : 1;
+    const int nprod = (!gather && (VP > 32 || vocab < 32 || CTCFA_TWO_PROD32 || CTCFA_ADDTID_PRODUCER)) ? 2 : 1;
     return label_column_limit(eng->lds_limit, VP, nprod, gather);
 }
 
@@ -641,7 +641,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->gather = gather;
     // Every vocabulary but the 32-entry one (whose rows a single wave moves with four wide loads per block) takes
     // two producer waves, each staging half the rows of every block: one alone cannot keep six tiles fed.
-    const int nprod = (!gather && (pl->VP > 32 || vocab < 32 || CTCFA_TWO_PROD32)) ? 2 : 1;
+    const int nprod = (!gather && (pl->VP > 32 || vocab < 32 || CTCFA_TWO_PROD32 || CTCFA_ADDTID_PRODUCER)) ? 2 : 1;
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.
@@ -1122,7 +1122,9 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
     bp.scorers = pl->ckpt ? pl->bt_scorers : 0;
     // Beside the fill of the next batch the striders run below the fill's tiles (config 3: 0.174 -> 0.165 ms per
     // step; a tile that loses an issue slot holds up every tile to its right), alone at the top.
-    bp.prio = beside_fill ? 0 : 3;
+    // (round 4: with the 32-entry fill 12 % faster the step was bound by the striders at priority 0 -- 0.1683 ms against
+    // 0.1571 at priority 1, the producers' level; vocabulary 29: 0.1799 / 0.1655; 38 and 64: +- 1 %; profiles/r04_strider_knobs.txt)
+    bp.prio = beside_fill ? 1 : 3;
     if (const char* e = std::getenv("CTCFA_SB_PRIO")) bp.prio = std::max(0, std::min(3, std::atoi(e)));
     bp.windows = 2;
     if (const char* e = std::getenv("CTCFA_SB_WINDOWS")) bp.windows = std::max(1, std::min(3, std::atoi(e)));

@@ -64,6 +64,9 @@
                       // (exchange rows, counters, waits for the neighbour), 2 the waits between tiles and producer (staged / ring space),
                       // 4 the trace-word and last-column stores, 8 the producer's work (it leaves at once; needs 2)
 #endif
+#ifndef CTCFA_ADDTID_PRODUCER
+#define CTCFA_ADDTID_PRODUCER 1   // the 32-entry vocabulary: two producers, one ds_write_addtid_b32 per ring row (0: one producer, 16-byte stores)
+#endif
 #ifndef CTCFA_PROD_PACE
 #define CTCFA_PROD_PACE 0   // s_sleep argument (x 64 clocks) between two LDS stores of a producer in the steady state (0: back to back)
 #endif
@@ -186,18 +189,21 @@ constexpr int kGroups = kRows / kHaloRows;
 #endif
 constexpr int kPollLead = CTCFA_POLL_LEAD;   // a tile reads its neighbour's counter and exchange row this many rows before the group's end (where it looks at them)
 constexpr int kExchangeRing = 8;    // group slots of a tile's exchange ring (ring slots NS <= 4, two groups per block)
-constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, always-done [19], pad
+constexpr int kFlagInts = 32;       // done[16], staged[2], posflag, always-done [19], a bounded wait gave up [20], pad
 constexpr int kBigCount = 0x3fffffff;
 constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a lost counter must not hang the GPU
 #ifdef CTCFA_DEBUG_SPIN
 #define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) printf("fill spin timeout: %s wg %d a %d b %d c %d T %d C %d\n", what, (int)blockIdx.x, (int)(a), (int)(b), (int)(c), T, C); } while (0)
 #else
-// a wait on a progress counter gave up (a lost counter would otherwise hang the GPU): this run's number goes into the
-// workspace's error word; the backtrack of the same run turns it into status CTCFA_ST_INTERNAL for the batch
-#define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) atomicExch(fill_err, run_id); } while (0)
+// a wait on a progress counter gave up (a lost counter would otherwise hang the GPU): flags[20] is raised HERE (an LDS word: no vector-memory operation in the loops the
+// compiler would then drain vmcnt for -- with one in a producer's bounded wait it waited for every load in flight at the
+// next join, taken or not), and every wave that leaves looks at it and writes this run's number into the workspace's
+// error word (CTCFA_SPIN_REPORT); the backtrack of the same run turns that into status CTCFA_ST_INTERNAL for the batch
+#define CTCFA_SPIN_DIAG(what, a, b, c) do { if ((threadIdx.x & 63) == 0) flags[20] = 1; } while (0)
 #endif
 
 using lds_vint = volatile __attribute__((address_space(3))) int;   // counters in LDS
+#define CTCFA_SPIN_REPORT() do { if ((threadIdx.x & 63) == 0 && flags[20] != 0) __hip_atomic_store(fill_err, run_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 
 // CTCFA_STAMP=4 (tuning builds): a TIMELINE -- every tile leaves an s_memtime stamp at the end of every 16-row group, the
 // producers one per block they publish and one per wait for ring space, for the first kTraceWgs workgroups; plus the
@@ -413,8 +419,18 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const int svc = sv < V ? sv : V - 1;
                 int t = t0 + idx / VP;
                 t = t < T ? t : T - 1;                 // rows past the end: re-read, discarded below
-                e[q] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V + svc) * 4u);
+                const uint32_t off = static_cast<uint32_t>(t * V + svc) * 4u;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(e[q]) : "v"(off), "s"(seg_lpz) : "memory");   // (inline asm: see chunk_await)
             }
+        };
+        // round 4: the wait for a chunk's loads, explicit (the compiler's own, in front of a block's first use, was for the
+        // NEXT block's loads too): with the next chunk's CH loads in flight behind them, this chunk's are there at vmcnt(CH)
+        auto chunk_await = [&](float (&e)[CH]) {
+            if constexpr (CH == 8)
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
+            else
+#pragma unroll
+                for (int q = 0; q < CH; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[q]));
         };
         auto write_chunk = [&](int jb, int p0, const float (&e)[CH]) {
             unsigned char* slot = smem + (jb % NS) * SLOT_BYTES;
@@ -443,7 +459,87 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
             }
         };
-        if ((VP == 32 || VP == 64) && V == VP) {  // (constant-folded away for the other pitches)
+        if (VP == 32 && V == 32 && CTCFA_ADDTID_PRODUCER && roles->nprod == 2) {
+            // ---- round 4: the 32-entry vocabulary staged ONE ROW PER STORE.  What the producer costs the tiles is the path its
+            // LDS stores share with the loads of its SIMD pair (2 cycles per register dword moved: 13 per ds_write_b128, eight of
+            // them per block): ds_write_addtid_b32 has no address register -- the address is M0 + offset + 4 * lane -- and moves
+            // one dword per lane in 2 cycles, and a ring row IS 64 consecutive dwords: its 32 (e, m) pairs.  So lane i loads
+            // entry i >> 1 of the row (one coalesced dword load, every entry twice), every lane works out m = max3(blank, e, -1e9),
+            // odd lanes keep m, even lanes e, and the row leaves in one store.  More instructions per block than the 16-byte
+            // path (8 per row), so two producers share a block: the upper and the lower 16 rows, two register sets each.
+            fix_mode = 3;
+            constexpr int NR = kRows / 2;
+            const int ent = lane >> 1;
+            const bool odd = (lane & 1) != 0;
+            // The loads are inline asm and so are the waits for them: left to the compiler, the wait in front of a block's
+            // first use was vmcnt(0..3) -- for the loads of the NEXT block too, issued a moment before: a memory round trip in
+            // every block of a wave the tiles wait for (trace4: the producer took 2 800 of a block's 3 400 cycles).  vmcnt
+            // retires in order: with the next block's NR loads in flight behind them, this block's are there at vmcnt(NR).
+            auto aload = [&](int jb, float (&e)[NR]) {
+                const int t0 = jb * kRows + 1 + part * NR;
+                if (t0 + NR <= T) {   // (uniform) all 16 rows inside the segment: one address register, the rows as immediates (V == 32: 128 bytes a row)
+                    const uint32_t off = static_cast<uint32_t>(t0 * 32 + ent) * 4u;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(e[r]) : "v"(off), "s"(seg_lpz), "i"(r * 128) : "memory");
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        int t = t0 + r;
+                        t = t < T ? t : T - 1;   // rows past the end repeat the last row: nothing downstream reads what the tiles make of them
+                        const uint32_t off = static_cast<uint32_t>(t * 32 + ent) * 4u;
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(e[r]) : "v"(off), "s"(seg_lpz) : "memory");
+                    }
+                }
+            };
+            auto await = [&](float (&e)[NR]) {   // (the registers pass through the asm: nothing that reads them moves above it)
+                static_assert(NR == 16, "the operand list below");
+                asm volatile("s_waitcnt vmcnt(16)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                             "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
+            };
+            auto awrite = [&](int jb, const float (&e)[NR], auto pre_tag) {
+                constexpr bool PRE = decltype(pre_tag)::value;   // preamble_transition_cost_zero (the default): no per-row start-column store
+                const uint32_t rowbase = static_cast<uint32_t>((jb % NS) * SLOT_BYTES + part * NR * ROW_BYTES);   // wave-uniform: M0
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), 2 * blank));
+                    notneg |= !(e[r] <= 0.0f);
+                    const float m = max3f(lb, e[r], kProbMax);
+                    const float v = odd ? m : e[r];
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2"
+                                 :: "v"(v), "s"(rowbase), "i"(r * ROW_BYTES) : "memory");   // (M0 is reserved: the compiler sets it right before each use of its own and keeps nothing in it)
+                    if (!PRE && lane == 0)   // start-column pseudo entry of the row (under preamble_transition_cost_zero: once, below)
+                        *reinterpret_cast<float2*>(smem + rowbase + static_cast<uint32_t>(r * ROW_BYTES + VP * 8)) =
+                            make_float2(-__builtin_inff(), __builtin_fmaxf(lb, kProbMax));
+                }
+            };
+            if (preamble && part == 0)   // start-column entry (e = -inf, stay step 0) of every row of the ring, once
+                for (int idx = lane; idx < NS * kRows; idx += 64)
+                    *reinterpret_cast<float2*>(smem + static_cast<uint32_t>((idx / kRows) * SLOT_BYTES + (idx % kRows) * (PITCH * 8) + VP * 8)) =
+                        make_float2(-__builtin_inff(), 0.0f);
+            auto arun = [&](auto pre_tag) {
+                // (a next set is ALWAYS in flight behind the one waited for -- past the last block its loads are issued once more,
+                // 16 x 256 bytes a segment -- so that one wait, vmcnt(16), serves every block)
+                float ea[NR], eb[NR];
+                aload(0, ea);
+                for (int jb = 0; jb < nblk; jb += 2) {
+                    aload(jb + 1 < nblk ? jb + 1 : nblk - 1, eb);
+                    wait_space(jb);
+                    await(ea);
+                    awrite(jb, ea, pre_tag);
+                    publish(jb);
+                    if (jb + 1 >= nblk) break;
+                    aload(jb + 2 < nblk ? jb + 2 : nblk - 1, ea);
+                    wait_space(jb + 1);
+                    await(eb);
+                    awrite(jb + 1, eb, pre_tag);
+                    publish(jb + 1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the set nobody uses: its registers must not be handed on with a load pending)
+            };
+            if (preamble) arun(std::true_type{});
+            else arun(std::false_type{});
+        } else if ((VP == 32 || VP == 64) && V == VP) {  // (constant-folded away for the other pitches)
             // ---- vectorised staging (the common case V == 32): a lane loads 4 consecutive
             // entries of a row with one dwordx4, LPR lanes share a row, RPP rows per pass.
             constexpr int LPR = VP / 4;
@@ -557,15 +653,26 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             auto run = [&](auto parts_tag) {
                 constexpr int PARTS = decltype(parts_tag)::value;
                 constexpr int NR = kRows / PARTS;  // rows of a block this wave stages: part, part + PARTS, ..
+                // (round 4: loads and the wait for them in inline asm, as in the 32-entry producer above -- the compiler's own wait
+                // in front of a block's first use was for the NEXT block's loads too; the row address is wave-uniform: an SGPR pair)
+                const uint32_t lane_off = static_cast<uint32_t>(svl) * 4u;
                 auto rload = [&](int jb, float (&e)[NR]) {
                     const int t0 = jb * kRows + 1 + part;
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         int t = t0 + i * PARTS;
                         t = t < T ? t : T - 1;
-                        e[i] = *reinterpret_cast<const float*>(lpz_bytes + static_cast<uint32_t>(t * V) * 4u +
-                                                               static_cast<uint32_t>(svl) * 4u);
+                        const float* rowp = seg_lpz + static_cast<uint32_t>(t * V);
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(e[i]) : "v"(lane_off), "s"(rowp) : "memory");
                     }
+                };
+                auto rawait = [&](float (&e)[NR]) {   // this wave's set of NR loads is there once only the NR issued after it are in flight
+                    if constexpr (NR == 16)
+                        asm volatile("s_waitcnt vmcnt(16)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                                     "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
+                    else
+#pragma unroll
+                        for (int i = 0; i < NR; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[i]));
                 };
                 auto rwrite = [&](int jb, const float (&e)[NR]) {
                     unsigned char* dst = smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) + ent +
@@ -584,25 +691,30 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 if constexpr (PARTS == 2) {
                     // two register sets of 16 rows: the loads of a block are issued a whole block before
                     // they are written (HBM latency never sits inside the staging of a block)
+                    // (a next set is always in flight behind the one waited for: past the last block its loads are issued again)
                     float ea[NR], eb[NR];
                     rload(0, ea);
                     for (int jb = 0; jb < nblk; jb += 2) {
-                        if (jb + 1 < nblk) rload(jb + 1, eb);
+                        rload(jb + 1 < nblk ? jb + 1 : nblk - 1, eb);
                         wait_space(jb);
+                        rawait(ea);
                         rwrite(jb, ea);
                         publish(jb);
                         if (jb + 1 >= nblk) break;
-                        if (jb + 2 < nblk) rload(jb + 2, ea);
+                        rload(jb + 2 < nblk ? jb + 2 : nblk - 1, ea);
                         wait_space(jb + 1);
+                        rawait(eb);
                         rwrite(jb + 1, eb);
                         publish(jb + 1);
                     }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the set nobody uses)
                 } else {
                     // One register set: the loads of block jb+1 are issued right after block jb has been written.
                     float ea[NR];
                     rload(0, ea);
                     for (int jb = 0; jb < nblk; ++jb) {
                         wait_space(jb);
+                        rawait(ea);
                         rwrite(jb, ea);
                         publish(jb);
                         if (jb + 1 < nblk) rload(jb + 1, ea);
@@ -623,16 +735,19 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             float ea[CH], eb[CH];
             load_chunk(0, p0, ea);
             for (int jb = 0; jb < nblk; jb += 2) {
-                if (jb + 1 < nblk) load_chunk(jb + 1, p0, eb);
+                load_chunk(jb + 1 < nblk ? jb + 1 : nblk - 1, p0, eb);   // (past the last block: its loads once more, so that one wait serves every block)
                 wait_space(jb);
+                chunk_await(ea);
                 write_chunk(jb, p0, ea);
                 publish(jb);
                 if (jb + 1 >= nblk) break;
-                if (jb + 2 < nblk) load_chunk(jb + 2, p0, ea);
+                load_chunk(jb + 2 < nblk ? jb + 2 : nblk - 1, p0, ea);
                 wait_space(jb + 1);
+                chunk_await(eb);
                 write_chunk(jb + 1, p0, eb);
                 publish(jb + 1);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the set nobody uses)
         } else if constexpr (VP > 64 && !E_ALONE) {
             // ---- character vocabularies between 65 and 80 entries (e.g. 76 for French), (e, m) pairs as below 64: a row per
             // pass, lane i holds entries i and 64 + i; lane 0 also writes the start-column pseudo entry.
@@ -765,6 +880,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                         -__builtin_inff();
             runw(std::integral_constant<int, 2>{});   // (the plan always gives these vocabularies two producers)
         }
+        CTCFA_SPIN_REPORT();
         return;
     }
 
@@ -1274,6 +1390,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             seg_lastcol[t] = *reinterpret_cast<const float*>(smem + lcring_base + ((jlast & 1) * kRows + lane) * 4);
     }
     if (lane == 63) flags[w] = kBigCount;   // done (end of the segment or dead zone): nobody waits for this tile again
+    CTCFA_SPIN_REPORT();
 #ifdef CTCFA_STAMP
     if (lane == 0 && blockIdx.x < 64) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(lastcol) + (blockIdx.x * 16 + w) * 8;
