@@ -258,7 +258,12 @@ int ctcfa_align_batch_spans(ctcfa_engine* eng, const ctcfa_params* params, int32
 
 /* Plan for the same geometry (ctcfa_plan_run_device / _pipelined then take `d_lpz` with the shared
  * blocks once).  labels: HOST array of all segments' labels back to back, used to check the prefix
- * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes. */
+ * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes.
+ * With labels given and nothing actually shared (emission_of[b] == b throughout is fine), a vocabulary of 33 .. 256 entries
+ * whose segments use at most 31 labels each beside the blank gets a NARROWED plan: the trellis fill runs through the
+ * 32-entry kernel on the 32 columns each segment looks at (the reference's 38-token character model: the pace of a 32-entry
+ * vocabulary).  The labels of every run of such a plan must be the ones it was created with; the host-buffer entries
+ * (ctcfa_align_batch*) narrow by themselves.  CTCFA_NO_NARROW=1 switches it off. */
 int ctcfa_plan_create_shared(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
                              int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
                              const int32_t* emission_of, const int32_t* labels, int32_t force_cols_per_lane);

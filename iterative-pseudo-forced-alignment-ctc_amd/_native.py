@@ -318,12 +318,17 @@ class Plan:
 
     def __init__(self, engine, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None):
         """emission_of / labels: ``ctcfa_plan_create_shared`` (segments that share emissions; ``labels`` =
-        all segments' labels back to back, for the prefix check, or None)."""
+        all segments' labels back to back, for the prefix check and for narrowing, or None)."""
         self._eng = engine
         self._lib = engine._lib
         T, C = _i32(T), _i32(C)
         U = _i32(U) if U is not None else None
         h = ctypes.c_void_p()
+        if emission_of is None and labels is not None:
+            # labels alone: nothing shared, but the plan may look at the texts -- a vocabulary above 32 entries whose
+            # segments use at most 31 labels each runs through the 32-entry fill kernel (a NARROWED plan); the labels of
+            # every later run must then be these
+            emission_of = np.arange(len(T), dtype=np.int32)
         if emission_of is None:
             rc = self._lib.ctcfa_plan_create(engine._h, ctypes.byref(h), ctypes.byref(params), len(T), int(vocab),
                                              _i32p(T), _i32p(C), _i32p(U), int(force_cols_per_lane))

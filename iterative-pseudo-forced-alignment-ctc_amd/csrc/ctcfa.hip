@@ -71,6 +71,9 @@ struct ctcfa_plan {
     int64_t total_T = 0, total_C = 0, total_U = 0, bits_words = 0, alg_bytes = 0;
     SegDesc* d_segs = nullptr;
     bool scratch_owned = false;  // d_segs / d_roles / d_bits[0] / d_lastcol[0] live in the engine's scratch
+    int VPbt = 0;                       // pitch of the checkpoint-mode backtrack (the vocabulary's own; VP is the FILL's: 32 for a narrowed plan)
+    std::vector<int32_t> narrow;        // narrowed plan: per workgroup (sorted order) 32 + V ints, see ctcfa::fill_kernel
+    int32_t* d_narrow = nullptr;
     // workspaces: index 0 always; the others exist once the pipelined entry has been used
     uint32_t* d_bits[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
     float* d_lastcol[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
@@ -88,7 +91,7 @@ struct ctcfa_plan {
     int ev_stride = 1;       // record timing events on every ev_stride-th run
     int64_t run_counter = 0;
     void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int) = nullptr;
+                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int, const int32_t*) = nullptr;
     int32_t last_run[kWorkspaces] = {0, 0, 0, 0};   // number of the run that last filled workspace q (its backtrack looks for it in the error word)
     // shared fills: watch columns of every group, the widest group, unique emission frames
     std::vector<ctcfa::WatchDesc> watch;
@@ -181,7 +184,8 @@ FillFn select_fill(int K, int VP, bool ck) {
 }
 
 using StrideFn = void (*)(ctcfa::BtArgs);
-StrideFn select_strider(int VP) {
+StrideFn select_strider(int VP, bool narrow = false) {
+    if (narrow) return VP == 32 ? ctcfa::stride_backtrack_kernel<32, true> : nullptr;
     switch (VP) {
         case 32: return ctcfa::stride_backtrack_kernel<32>;
 #ifndef CTCFA_DEV_VP32_ONLY
@@ -433,7 +437,7 @@ int ctcfa_build_flags(void) {
 #ifdef CTCFA_DEV_VP32_ONLY
     f |= CTCFA_BUILD_ONE_PITCH;
 #endif
-#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || CTCFA_MASKED_PUBLISH != 1 || CTCFA_OWNER_DEFER != 0 || CTCFA_LEAN_HANDOVER != 1 || CTCFA_ADDTID_PRODUCER != 1 || \
+#if defined(CTCFA_NO_DEADZONE) || defined(CTCFA_DEBUG_SPIN) || CTCFA_PF != 2 || CTCFA_POLL_LEAD != 4 || CTCFA_BODY_BLOCKS != 2 || CTCFA_PROD_PACE != 0 || CTCFA_MASKED_PUBLISH != 1 || CTCFA_OWNER_DEFER != 0 || CTCFA_LEAN_HANDOVER != 1 || CTCFA_ADDTID_PRODUCER != 1 || CTCFA_LEAN_ALL_PITCHES != 0 || \
     CTCFA_NBR_SLEEP != 1 || CTCFA_TWO_PROD32 != 0 || CTCFA_VGPR_CAP != 1 || CTCFA_PRODUCER_PRIO != 1 || CTCFA_TILE_PRIO_BASE != 2 || CTCFA_TRACE_NT != 1 || CTCFA_SB_RING != 8 || CTCFA_SB_MARGIN != 15
     f |= CTCFA_BUILD_RETUNED;
 #endif
@@ -529,7 +533,9 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
         plan->d_win_list = nullptr;
         plan->d_win_table = nullptr;
         plan->d_win_offs = nullptr;
+        plan->d_narrow = nullptr;
     }
+    if (plan->d_narrow) (void)hipFree(plan->d_narrow);
     if (plan->d_watch) (void)hipFree(plan->d_watch);
     if (plan->d_segs) (void)hipFree(plan->d_segs);
     if (plan->d_roles) (void)hipFree(plan->d_roles);
@@ -596,10 +602,12 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // blank while the package's backtrack still assumes max(blank, label) -- only checkpoint mode keeps
     // the two apart (the decision words of the other mode are computed with the fill's step)
     const bool gratis = (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) != 0;
-    if (gratis && vocab > 64)
-        return set_err(eng, CTCFA_ERR_UNSUPPORTED,
-                       "blank_transition_cost_zero needs a vocabulary of at most 64 entries (the host-buffer and resident entries "
-                       "also take larger ones whose launch looks at no more than 63 distinct labels)");
+    static const char* const kGratisWide =
+        "blank_transition_cost_zero needs a vocabulary of at most 64 entries, or a plan created with its labels whose texts use at "
+        "most 31 entries each beside the blank (the host-buffer and resident entries also take larger ones whose launch looks at "
+        "no more than 63 distinct labels)";
+    if (gratis && vocab > 64 && !(labels && label_width == 1 && vocab <= kMaxStagedVocab))   // (a narrowed plan takes it: decided below)
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, kGratisWide);
     if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > kMaxScoreLength)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1, 1048576]");
     // wide vocabularies (sub-word models) take the gather kernel: no LDS staging of vocabulary rows
@@ -641,7 +649,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     pl->gather = gather;
     // Every vocabulary but the 32-entry one (whose rows a single wave moves with four wide loads per block) takes
     // two producer waves, each staging half the rows of every block: one alone cannot keep six tiles fed.
-    const int nprod = (!gather && (pl->VP > 32 || vocab < 32 || CTCFA_TWO_PROD32 || CTCFA_ADDTID_PRODUCER)) ? 2 : 1;
+    int nprod = (!gather && (pl->VP > 32 || vocab < 32 || CTCFA_TWO_PROD32 || CTCFA_ADDTID_PRODUCER)) ? 2 : 1;
+    pl->VPbt = pl->VP;
     // What the shapes alone decide, per segment (the package's assertion and window rule): only the
     // segments that go through the fill kernel count for its launch shape -- one over-long text in a
     // batch is that segment's status, not the batch's failure.
@@ -692,6 +701,47 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         for (int b = 0; b < batch; ++b)
             if (members[b]) nwatch_bound = std::max(nwatch_bound, members[b] + 1);
     }
+    // Narrowed plan (round 4): a vocabulary of 33 .. 256 entries whose texts -- every segment's own -- use at most 31 of them
+    // beside the blank runs through the 32-ENTRY fill kernel: per segment a table (ring entry -> vocabulary entry, entry 0 the
+    // blank; vocabulary entry -> ring entry), applied by the producers when they stage a row and by the tiles when they look
+    // up their labels.  A character model's window does (the reference's 38-token model; `bench.py --vocab 38 --alphabet 28`);
+    // needs the labels on the host (the host-buffer entries; ctcfa_plan_create_shared with labels) and no shared fills.
+    std::vector<int32_t> narrow_by_b;
+    if (!gather && CTCFA_ADDTID_PRODUCER && label_width == 1 && labels && nwatch_bound == 0 && vocab > 32 && vocab <= kMaxStagedVocab &&
+        params->blank >= 0 && params->blank < vocab && !std::getenv("CTCFA_NO_NARROW")) {
+        const int stride = 32 + vocab;
+        narrow_by_b.assign((size_t)batch * stride, 0);
+        bool ok = true;
+        int64_t o = 0;
+        for (int b = 0; b < batch && ok; o += C[b], ++b) {
+            int32_t* map = narrow_by_b.data() + (size_t)b * stride;
+            int32_t* inv = map + 32;
+            for (int q = 0; q < 32; ++q) map[q] = params->blank;
+            if (pre[b] != CTCFA_ST_OK) continue;
+            int used = 1;   // ring entry 0: the blank
+            std::vector<int8_t> seen(vocab, 0);
+            seen[params->blank] = 1;
+            for (int c = 1; c < C[b]; ++c) {
+                const int32_t g = labels[o + c];
+                if (g < 0 || g >= vocab) { ok = false; break; }   // (such a segment never gets here through the Python mirror; not ours to judge)
+                if (seen[g]) continue;
+                if (used == 32) { ok = false; break; }
+                seen[g] = 1;
+                map[used] = g;
+                inv[g] = used++;
+            }
+        }
+        if (!ok) narrow_by_b.clear();
+    }
+    if (!narrow_by_b.empty()) {   // fill and checkpoint-mode backtrack stage the table's 32 entries of a row
+        pl->VP = 32;
+        pl->VPbt = 32;
+        nprod = 2;
+    }
+    if (gratis && vocab > 64 && narrow_by_b.empty()) {
+        delete pl;
+        return set_err(eng, CTCFA_ERR_UNSUPPORTED, kGratisWide);
+    }
     auto n_fill_of = [&]() {
         int n = 0;
         for (int b = 0; b < batch; ++b) n += (pre[b] == CTCFA_ST_OK && leader[b] == b);
@@ -703,7 +753,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // for: many label columns per segment, or enough segments per CU.
     // CTCFA_CHECKPOINT=1 / CTCFA_DECISION_BITS=1 force one mode (tests, tuning).
     {
-        const bool can = !gather && pl->VP <= 64;
+        const bool can = !gather && pl->VPbt <= 64;
         // (the host-buffer entry runs fill and backtrack one after the other: there the longer
         // backtrack only pays once the fill is several times its length)
         const int64_t nf = n_fill_of();
@@ -731,7 +781,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     {
         const int Tb = Tmax;
         const int rec = ((Tb + ctcfa::kRows - 1) / ctcfa::kRows * 8 + 15) / 16 * 16;
-        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VP, strider_waves(batch <= eng->num_cu), Tb) : rec + Tb * 4;
+        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VPbt, strider_waves(batch <= eng->num_cu), Tb) : rec + Tb * 4;
     }
     ShapeChoice shape{0, 0, 0};
     if (gather) {
@@ -892,9 +942,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             pl->bt_waves = strider_waves(batch <= eng->num_cu);
             pl->bt_scorers = (pl->have_utt && !std::getenv("CTCFA_SB_NO_SCORER")) ? 1 : 0;
             pl->fol_bytes = 4 * pl->lab_bytes;
-            pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VP, pl->bt_waves, Tbt);
+            pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VPbt, pl->bt_waves, Tbt);
             while (pl->lds_bt > eng->lds_limit && pl->bt_waves > 1)   // (a very long lone segment: fewer slots rather than no plan)
-                pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VP, --pl->bt_waves, Tbt);
+                pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VPbt, --pl->bt_waves, Tbt);
         }
     }
     if (pl->lds_bt > eng->lds_limit) {
@@ -918,6 +968,13 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         for (int i = 0; i < batch; ++i) pos[sorted[i].seg_index] = i;
         for (auto& w : pl->win_list) w = pos[w];   // (windowed_kernel indexes the table through this list)
         pl->segs.swap(sorted);
+    }
+
+    if (!narrow_by_b.empty()) {   // the narrowing tables in the workgroups' (sorted) order
+        const size_t stride = 32 + (size_t)vocab;
+        pl->narrow.resize((size_t)batch * stride);
+        for (int i = 0; i < batch; ++i)
+            std::memcpy(pl->narrow.data() + (size_t)i * stride, narrow_by_b.data() + (size_t)pl->segs[i].seg_index * stride, stride * sizeof(int32_t));
     }
 
 #define PLAN_TRY(expr)                                                                        \
@@ -949,6 +1006,10 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             PLAN_TRY(hipMalloc(&pl->d_watch, sizeof(ctcfa::WatchDesc) * pl->watch.size()));
             PLAN_TRY(hipMemcpy(pl->d_watch, pl->watch.data(), sizeof(ctcfa::WatchDesc) * pl->watch.size(), hipMemcpyHostToDevice));
         }
+        if (!pl->narrow.empty()) {
+            PLAN_TRY(hipMalloc(&pl->d_narrow, sizeof(int32_t) * pl->narrow.size()));
+            PLAN_TRY(hipMemcpy(pl->d_narrow, pl->narrow.data(), sizeof(int32_t) * pl->narrow.size(), hipMemcpyHostToDevice));
+        }
     }
     {   // The pipelined entry runs the backtrack of run k beside the fill of run k+1 -- where one fits beside the other.
         // Where not a single backtrack workgroup finds LDS (or registers: the 256-entry kernels take 128, two workgroups
@@ -966,7 +1027,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
     if (pl->lds_bt > 48 * 1024)
         PLAN_TRY(hipFuncSetAttribute(!pl->ckpt ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel)
-                                                : reinterpret_cast<const void*>(select_strider(pl->VP)),
+                                                : reinterpret_cast<const void*>(select_strider(pl->VPbt, !pl->narrow.empty())),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
     if (!pl->win_list.empty()) {
         if (use_scratch) {
@@ -1093,7 +1154,7 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
 #else
                           reinterpret_cast<int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
 #endif
-                          (int)pl->last_run[ws]);
+                          (int)pl->last_run[ws], (const int32_t*)pl->d_narrow);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }
@@ -1133,7 +1194,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
                            pl->d_lastcol[ws],
                            pl->gather ? nullptr : reinterpret_cast<const int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
                            pl->last_run[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
-                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
+                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status, (const int32_t*)pl->d_narrow};
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
                               start, (windowed || rescore) ? nullptr : stop, 0, ba);
@@ -1141,7 +1202,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         // (the LDS is sized for bt_waves; beside the next batch's fill even a lone launch keeps to three striders:
         // 64 / 128 / 256 segments pipelined 0.1161 / 0.1167 / 0.1178 ms per step with three, 0.1165 / 0.1178 / 0.1190 with seven)
         const int striders = (beside_fill && !std::getenv("CTCFA_SB_WAVES")) ? std::min(pl->bt_waves, 3) : pl->bt_waves;
-        hipExtLaunchKernelGGL(select_strider(pl->VP), dim3(pl->B), dim3(64 * (striders + pl->bt_scorers)), pl->lds_bt, st,
+        hipExtLaunchKernelGGL(select_strider(pl->VPbt, pl->d_narrow != nullptr), dim3(pl->B), dim3(64 * (striders + pl->bt_scorers)), pl->lds_bt, st,
                               start, (windowed || rescore) ? nullptr : stop, 0, ba);
     }
     HIP_TRY(pl->eng, hipGetLastError());
@@ -1419,7 +1480,14 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     // through the gather kernel (tools/wide_vocab_timing.py) and skip the pre-pass.  CTCFA_REMAP=1 forces it.
     bool remap_wanted = false;
     const bool gratis_call = params && (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO);
-    if (vocab > kMaxStagedVocab && label_width == 1 && params && T && C) {
+    // (blank_transition_cost_zero over 65 .. 256 entries: a narrowed plan takes the emissions as they are -- tried first)
+    ctcfa_plan* pl = nullptr;
+    int rc = CTCFA_ERR_UNSUPPORTED;
+    if (vocab > 64 && vocab <= kMaxStagedVocab && gratis_call && label_width == 1 && labels && T && C &&
+        !std::getenv("CTCFA_NO_NARROW") && !std::getenv("CTCFA_REMAP"))
+        rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of, labels, label_width);
+    if (rc == CTCFA_OK) {
+    } else if (vocab > kMaxStagedVocab && label_width == 1 && params && T && C) {
         int cmax = 0;
         for (int b = 0; b < batch; ++b) cmax = std::max(cmax, (int)C[b]);
         remap_wanted = cmax >= 192 || !(params->flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) || gratis_call ||
@@ -1437,8 +1505,8 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
         labels = remap.labels.data();
         vocab = remap.Vc;
     }
-    ctcfa_plan* pl = nullptr;
-    int rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of,
+    if (rc != CTCFA_OK)
+        rc = plan_create_impl(eng, &pl, params, batch, vocab, T, C, U, 0, true, emission_of,
                               label_width > 1 ? nullptr : labels, label_width);
     if (rc != CTCFA_OK) return rc;
     lap(0);
@@ -1463,7 +1531,8 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     const size_t n_watch = pl->watch.size();
     const size_t in_roles = 0, in_segs = up(sizeof(ctcfa::FillRoles)), in_lab = in_segs + up(sizeof(SegDesc) * (size_t)batch),
                  in_ub = in_lab + up(n_lab * 4 * (size_t)pl->S), in_watch = in_ub + (want_seg ? up(n_ub * 4) : 0),
-                 in_orig = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc)),
+                 in_narrow = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc)),
+                 in_orig = in_narrow + up(pl->narrow.size() * sizeof(int32_t)),
                  in_cblk = in_orig + (compact ? up(remap.orig.size() * 4) : 0),
                  in_bytes = in_cblk + (compact ? up(remap.blocks.size() * sizeof(ctcfa::CompactBlock)) : 0);
     const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
@@ -1491,6 +1560,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     std::memcpy(h + in_lab, labels, n_lab * 4 * (size_t)pl->S);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
     if (n_watch) std::memcpy(h + in_watch, pl->watch.data(), n_watch * sizeof(ctcfa::WatchDesc));
+    if (!pl->narrow.empty()) std::memcpy(h + in_narrow, pl->narrow.data(), pl->narrow.size() * sizeof(int32_t));
     if (compact) {
         std::memcpy(h + in_orig, remap.orig.data(), remap.orig.size() * 4);
         std::memcpy(h + in_cblk, remap.blocks.data(), remap.blocks.size() * sizeof(ctcfa::CompactBlock));
@@ -1514,6 +1584,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     pl->d_roles = reinterpret_cast<ctcfa::FillRoles*>(d_in + in_roles);
     pl->d_segs = reinterpret_cast<SegDesc*>(d_in + in_segs);
     pl->d_watch = n_watch ? reinterpret_cast<ctcfa::WatchDesc*>(d_in + in_watch) : nullptr;
+    pl->d_narrow = pl->narrow.empty() ? nullptr : reinterpret_cast<int32_t*>(d_in + in_narrow);
     int32_t* d_lab = reinterpret_cast<int32_t*>(d_in + in_lab);
     int32_t* d_ub = want_seg ? reinterpret_cast<int32_t*>(d_in + in_ub) : nullptr;
     double* d_seg = want_seg ? reinterpret_cast<double*>(d_out + o_seg) : nullptr;

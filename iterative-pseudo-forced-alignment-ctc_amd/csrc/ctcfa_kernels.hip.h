@@ -78,6 +78,9 @@
 #ifndef CTCFA_LEAN_HANDOVER
 #define CTCFA_LEAN_HANDOVER 1    // 32-entry pitch: counter and exchange row read together 4 rows before a group's end, looked at at its end; 0 = rounds 2-3 everywhere
 #endif
+#ifndef CTCFA_LEAN_ALL_PITCHES
+#define CTCFA_LEAN_ALL_PITCHES 0  // tuning: the lean hand-over and the two-block bodies for every (e, m)-pair pitch up to 64 entries
+#endif
 #ifndef CTCFA_MASKED_PUBLISH
 #define CTCFA_MASKED_PUBLISH 1   // 1 = two-column tiles store their exchange row under an exec mask (rounds 2-3); 0 = every lane stores (the rest into the sink)
 #endif
@@ -279,7 +282,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int cost_flags,
             const FillRoles* __restrict__ roles, const WatchDesc* __restrict__ watch,
-            int32_t* __restrict__ fill_err, int run_id) {
+            int32_t* __restrict__ fill_err, int run_id, const int32_t* __restrict__ narrow) {
+    // narrow (32-entry pitch only; NULL otherwise): a NARROWED plan -- the vocabulary has more than 32 entries, but no segment's
+    // text uses more than 31 of them beside the blank (a character model's windows: the reference's 38-token model).  Per
+    // workgroup 32 + V ints: ring entry -> vocabulary entry (entry 0 = the blank), vocabulary entry -> ring entry.  The
+    // producers stage the 32 columns a segment looks at, the tiles address the ring by ring entry: the fill runs at the
+    // 32-entry pace whatever the vocabulary; the backtrack works on the emissions themselves and never sees the ring.
     // cost_flags: bit 0 = preamble_transition_cost_zero (column 0 stays for free), bit 1 =
     // blank_transition_cost_zero (a column labelled blank stays for free: the blank entry's m is 0)
     const bool preamble = (cost_flags & 1) != 0;
@@ -310,6 +318,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
+    const int32_t* __restrict__ nrw = (VP == 32 && narrow) ? narrow + static_cast<int64_t>(blockIdx.x) * (32 + V) : nullptr;
+    const int rblank = nrw ? 0 : blank;   // the blank's entry of the RING
     const int wn = (K <= kWatchMaxK) ? sd.watch_n : 0;   // watch columns of a shared fill
     const WatchDesc* __restrict__ seg_watch = watch + sd.watch_first;
 
@@ -395,7 +405,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                 : fix_mode == 3 ? part * (kRows / 2) + lane : part + 2 * lane;
                 if (lane < nmine)
                     *reinterpret_cast<float*>(smem + static_cast<uint32_t>((jb % NS) * SLOT_BYTES) +
-                                              static_cast<uint32_t>(row * (PITCH * 8) + blank * 8 + 4)) = 0.0f;
+                                              static_cast<uint32_t>(row * (PITCH * 8) + rblank * 8 + 4)) = 0.0f;
             }
             if (__builtin_amdgcn_ballot_w64(notneg) != 0ull) *posflag = 1;
             asm volatile("" ::: "memory");  // data and posflag first, then the counter (LDS executes a wave's operations in order)
@@ -459,7 +469,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
             }
         };
-        if (VP == 32 && V == 32 && CTCFA_ADDTID_PRODUCER && roles->nprod == 2) {
+        if (VP == 32 && (V == 32 || nrw != nullptr) && CTCFA_ADDTID_PRODUCER && roles->nprod == 2) {
             // ---- round 4: the 32-entry vocabulary staged ONE ROW PER STORE.  What the producer costs the tiles is the path its
             // LDS stores share with the loads of its SIMD pair (2 cycles per register dword moved: 13 per ds_write_b128, eight of
             // them per block): ds_write_addtid_b32 has no address register -- the address is M0 + offset + 4 * lane -- and moves
@@ -469,7 +479,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // path (8 per row), so two producers share a block: the upper and the lower 16 rows, two register sets each.
             fix_mode = 3;
             constexpr int NR = kRows / 2;
-            const int ent = lane >> 1;
+            const int ent = nrw ? nrw[lane >> 1] : (lane >> 1);   // (a narrowed plan: the vocabulary entry behind ring entry lane >> 1)
             const bool odd = (lane & 1) != 0;
             // The loads are inline asm and so are the waits for them: left to the compiler, the wait in front of a block's
             // first use was vmcnt(0..3) -- for the loads of the NEXT block too, issued a moment before: a memory round trip in
@@ -477,7 +487,16 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // retires in order: with the next block's NR loads in flight behind them, this block's are there at vmcnt(NR).
             auto aload = [&](int jb, float (&e)[NR]) {
                 const int t0 = jb * kRows + 1 + part * NR;
-                if (t0 + NR <= T) {   // (uniform) all 16 rows inside the segment: one address register, the rows as immediates (V == 32: 128 bytes a row)
+                if (V != 32) {   // (a narrowed plan) rows of V entries: the row's address is wave-uniform, an SGPR pair; the lane offset one register
+                    const uint32_t lane_off = static_cast<uint32_t>(ent) * 4u;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        int t = t0 + r;
+                        t = t < T ? t : T - 1;
+                        const float* rowp = seg_lpz + static_cast<uint32_t>(t * V);
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(e[r]) : "v"(lane_off), "s"(rowp) : "memory");
+                    }
+                } else if (t0 + NR <= T) {   // (uniform) all 16 rows inside the segment: one address register, the rows as immediates (V == 32: 128 bytes a row)
                     const uint32_t off = static_cast<uint32_t>(t0 * 32 + ent) * 4u;
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
@@ -502,7 +521,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                 const uint32_t rowbase = static_cast<uint32_t>((jb % NS) * SLOT_BYTES + part * NR * ROW_BYTES);   // wave-uniform: M0
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), 2 * blank));
+                    const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), 2 * rblank));
                     notneg |= !(e[r] <= 0.0f);
                     const float m = max3f(lb, e[r], kProbMax);
                     const float v = odd ? m : e[r];
@@ -898,8 +917,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         const int c = pc - shift;
         int lab;
         if (c <= 0) lab = VP;                  // start column / left padding
-        else if (c < C) lab = seg_lab[c];
-        else lab = blank;                      // right padding: any valid entry
+        else if (c < C) lab = nrw ? nrw[32 + seg_lab[c]] : seg_lab[c];   // (a narrowed plan: the label's entry of the ring)
+        else lab = rblank;                     // right padding: any valid entry
         gaddr[k] = static_cast<uint32_t>(lab) * (E_ALONE ? 4u : 8u);
         startlike[k] = c <= 0;
         prev[k] = (c <= 0) ? 0.0f : kProbMax;  // table[0,0] = 0, table[0,c>0] = -1e9
@@ -937,7 +956,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // K <= 2: at a group's end EVERY lane stores (no branch, no exec-mask juggling): the lanes that publish nothing write into
     // the sink (their own 4 K bytes of it per exchange slot: lane * 4 K + 8 slots * 4 XW <= 1 KB), and every lane but the last
     // stores its copy of the counter there too (the last 256 bytes of the sink)
-    constexpr bool kLean = VP == 32 && CTCFA_LEAN_HANDOVER;   // (the other pitches: rounds 2-3's hand-over, below)
+    constexpr bool kLean = (VP == 32 || (CTCFA_LEAN_ALL_PITCHES && VP <= 64)) && CTCFA_LEAN_HANDOVER;   // (the other pitches: rounds 2-3's hand-over, below)
     constexpr bool kAllLanesPublish = K == 1 || (K == 2 && !CTCFA_MASKED_PUBLISH);
     const uint32_t xw_addr = (!kAllLanesPublish || publishes) ? xout_addr : sink_base + static_cast<uint32_t>(lane * K * 4);
     const uint32_t cnt_out_addr = (lane == 63) ? flag_base + static_cast<uint32_t>(w * 4) : sink_base + 1024u + static_cast<uint32_t>(lane * 4);
@@ -1318,7 +1337,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     };
     // two-block bodies: the (e, m) pair kernels (their loop overhead is what a narrow tile notices); a ring with an even
     // number of slots, a body that starts in an even slot, both blocks staged already, both inside the tile's live range
-    constexpr bool kPairs = VP == 32 && CTCFA_BODY_BLOCKS >= 2;
+    constexpr bool kPairs = (VP == 32 || (CTCFA_LEAN_ALL_PITCHES && VP <= 64)) && CTCFA_BODY_BLOCKS >= 2;
     const bool ring_even = (NS & 1) == 0;
     auto body = [&](int j, auto nb_tag) {
         if constexpr (K <= kWatchMaxK) {
@@ -1787,6 +1806,7 @@ struct BtArgs {
     double* seg_score;
     int32_t* t_end_out;
     int32_t* status_out;
+    const int32_t* narrow;     // narrowed plan: the fill kernel's per-segment tables (stride_backtrack_kernel<32, true>), else NULL
 };
 
 // NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
@@ -2110,7 +2130,10 @@ __device__ __forceinline__ void for_each_row(F&& f, std::integer_sequence<int, I
     (f(std::integral_constant<int, I>{}), ...);   // rows in order, the row number a compile-time constant
 }
 
-template <int P>   // LDS row pitch of a staged emission block (the vocabulary rounded up: 32 / 40 / 48 / 56 / 64)
+// NARROW (a narrowed plan, P = 32): a staged row holds the 32 vocabulary entries of the segment's table (entry 0 the blank)
+// instead of the whole vocabulary row -- gathered from lpz, four entries of four rows per lane -- and the label bytes are
+// ring entries: the vocabulary itself may have up to 256 entries.
+template <int P, bool NARROW = false>   // P: LDS row pitch of a staged emission block (the vocabulary rounded up: 32 / 40 / 48 / 56 / 64)
 __global__ void __launch_bounds__(64 * kSbMaxWaves, 5)   // <= 96 VGPRs: room beside the 64-register fill tiles of the next batch
 stride_backtrack_kernel(BtArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2132,6 +2155,8 @@ stride_backtrack_kernel(BtArgs a) {
     const float* __restrict__ seg_lpz = a.lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = a.labels + sd.lab_off;
     const uint32_t* __restrict__ seg_bits = a.bits + sd.bits_off;
+    const int32_t* __restrict__ nrw = NARROW ? a.narrow + (size_t)blockIdx.x * (size_t)(32 + V) : nullptr;
+    const int rblank = NARROW ? 0 : p.blank;   // the blank's place in a staged row
     int32_t* fol = a.frame_of_label + sd.lab_off;
     float* cp = a.char_prob + sd.frm_off;
     int32_t* st = a.state ? a.state + sd.frm_off : nullptr;
@@ -2219,7 +2244,7 @@ stride_backtrack_kernel(BtArgs a) {
     for (int c = tid; c < C; c += nthreads) {
         fol[c] = 0;
         fol_lds[c] = 0;
-        labs[c] = (uint8_t)seg_lab[c];  // [0] = -1 is never looked up
+        labs[c] = NARROW ? (uint8_t)nrw[32 + seg_lab[c]] : (uint8_t)seg_lab[c];  // [0] = -1 is never looked up (narrowed: reads table word 31)
     }
     for (int i = tid; i < kRows * P; i += nthreads) reinterpret_cast<float*>(smem + neg_base)[i] = -__builtin_inff();
     if (tid < 4) sh_misc[tid] = (tid == 3) ? U - 1 : 0;   // [3]: the next utterance to score (from the last one down)
@@ -2278,6 +2303,11 @@ stride_backtrack_kernel(BtArgs a) {
         int stg_n0 = 0;   // first element (of the segment's lpz) of the block in stg[]
         const int nmax = T * V - 4 > 0 ? T * V - 4 : 0;   // last place a dwordx4 load may start
         bool stg_blank_only = false;   // the block in stg[] lies in the start column: only its blank entries were asked for
+        int gcol[4] = {0, 0, 0, 0};    // narrowed: the vocabulary entries behind ring entries 4 (lane & 7) + k
+        if (NARROW) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gcol[k] = nrw[4 * (lane & 7) + k];
+        }
         auto issue = [&](int jb, bool blank_only = false) {
             const int n0 = (jb * kRows + 1) * V;
             stg_n0 = n0;
@@ -2290,6 +2320,16 @@ stride_backtrack_kernel(BtArgs a) {
                 stg[0].x = seg_lpz[t * V + p.blank];
                 return;
             }
+            if (NARROW) {   // quad q of lane l: ring entries 4 (l & 7) .. + 3 of row (l >> 3) + 8 q -- put()'s float4 layout at pitch 32
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    int t = jb * kRows + 1 + (lane >> 3) + 8 * q;
+                    t = t < T ? t : T - 1;   // (rows past the end of the segment: its last row again, nobody reads them)
+                    const float* __restrict__ rowp = seg_lpz + (size_t)t * (size_t)V;
+                    stg[q] = make_float4(rowp[gcol[0]], rowp[gcol[1]], rowp[gcol[2]], rowp[gcol[3]]);
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 int n = n0 + 4 * (lane + 64 * q);
@@ -2300,10 +2340,10 @@ stride_backtrack_kernel(BtArgs a) {
         };
         auto put = [&]() {
             if (stg_blank_only) {
-                if (lane < kRows) *reinterpret_cast<float*>(smem + my_slot + (uint32_t)((lane * P + p.blank) * 4)) = stg[0].x;
+                if (lane < kRows) *reinterpret_cast<float*>(smem + my_slot + (uint32_t)((lane * P + rblank) * 4)) = stg[0].x;
                 return;
             }
-            if (V == P) {
+            if (NARROW || V == P) {
                 // (rows past the end of the segment hold its last entries: nobody reads what becomes of them)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4*>(smem + my_slot + (uint32_t)((lane + 64 * q) * 16)) = stg[q];
@@ -2347,7 +2387,7 @@ stride_backtrack_kernel(BtArgs a) {
             const int lab = pseudo ? 0 : (int)labs[c];     // c <= C-1: the path never sits right of the end cell's column
             const bool pp = pseudo && preamble;
             const uint32_t ea = pseudo ? neg_base : my_slot + (uint32_t)lab * 4u;
-            const uint32_t la = pp ? neg_base : my_slot + (uint32_t)p.blank * 4u;
+            const uint32_t la = pp ? neg_base : my_slot + (uint32_t)rblank * 4u;
             const float flo = pp ? 0.0f : kProbMax;        // the start column stays for free under preamble_transition_cost_zero
             // emission operands: a ring of RH rows in registers, row i + RH requested while row i is computed
             constexpr int RH = CTCFA_SB_RING;
@@ -2361,7 +2401,7 @@ stride_backtrack_kernel(BtArgs a) {
             else if (col < 0) prev = 0.0f;                 // left of the padded table (feeds nothing that is read)
             // m: the stay step the package's BACKTRACK assumes (max(blank, label)); mf: the one the FILL charged
             // -- 0 in a column labelled blank under blank_transition_cost_zero, else m
-            const bool free_stay = gratis && !pseudo && lab == p.blank;
+            const bool free_stay = gratis && !pseudo && lab == rblank;
             uint32_t Sv = 0u;
             auto rows = [&](auto gratis_tag, auto first_tag) {
                 auto row = [&](auto row_tag) {
@@ -2572,7 +2612,7 @@ stride_backtrack_kernel(BtArgs a) {
                     const int pct = entry - __builtin_popcount(S & ((1u << b) - 1u));
                     const int sw = (S >> b) & 1u;
                     const int c = pct - shift;
-                    const float lbv = *reinterpret_cast<const float*>(smem + my_slot + (uint32_t)((i * P + p.blank) * 4));
+                    const float lbv = *reinterpret_cast<const float*>(smem + my_slot + (uint32_t)((i * P + rblank) * 4));
                     float prob;
                     int s_lab = -1;
                     if (c <= 0) {
@@ -2583,7 +2623,7 @@ stride_backtrack_kernel(BtArgs a) {
                         const float mx = __builtin_fmaxf(ev, kMaxProb);
                         if (sw) {
                             prob = mx;
-                            s_lab = g;
+                            s_lab = NARROW ? nrw[g] : g;   // (the state list names vocabulary entries)
                             fol[c] = t;
                             fol_lds[c] = t;
                         } else {

@@ -152,6 +152,80 @@ def test_vocabulary_sizes(pkg, oracle, V):
     _check(pkg, oracle, segs, _run(pkg, segs))
 
 
+@pytest.mark.parametrize("V", [33, 38, 48, 64, 100, 200, 256])
+def test_narrowed_plans(pkg, oracle, V, monkeypatch):
+    """A vocabulary above 32 entries whose texts use at most 31 labels each beside the blank (a character model's
+    windows: the reference's 38-token model) runs through the 32-entry fill kernel on the columns each segment looks at
+    (a NARROWED plan; the host-buffer entry narrows by itself): same results as the oracle, as the un-narrowed plan,
+    with every flag, with the blank elsewhere, and a batch with one text of more than 31 labels is simply not narrowed."""
+    syn = pkg.synthetic
+    shapes = [(400, 4, 20), (250, 2, 31), (64, 1, 10), (700, 6, 25), (1100, 9, 30)]
+    segs = [syn.make_segment(700 + s + V, T, V, U, n, alphabet=28 if s % 2 == 0 else 31) for s, (T, U, n) in enumerate(shapes)]
+    assert all(len(np.unique(g[1:])) <= 32 for _, g, _ in segs)
+    res = _run(pkg, segs)
+    _check(pkg, oracle, segs, res)
+    monkeypatch.setenv("CTCFA_NO_NARROW", "1")
+    plain = _run(pkg, segs)
+    monkeypatch.delenv("CTCFA_NO_NARROW")
+    for a, b in zip(res, plain):
+        for k in ("frame_of_label", "char_prob", "state", "seg_start", "seg_end", "seg_score", "t_end", "status"):
+            assert np.array_equal(a[k], b[k]), k
+    # flags: the start column pays for staying; the blank's stay step is free (checkpoint mode only: a narrowed plan's
+    # backtrack stages the same 32 entries, whatever the vocabulary)
+    _check(pkg, oracle, segs, _run(pkg, segs, preamble_transition_cost_zero=False), dict(preamble_transition_cost_zero=0))
+    _check(pkg, oracle, segs, _run(pkg, segs, blank_transition_cost_zero=True), dict(blank_transition_cost_zero=1))
+    _check(pkg, oracle, segs, _run(pkg, segs, backtrack_from_max_t=True), dict(backtrack_from_max_t=1))
+    # the blank somewhere else in the vocabulary (texts over entries 0 .. 27 then)
+    b = V - 1
+    moved = [syn.make_segment(900 + s + V, T, V, U, n, blank=b, alphabet=28) for s, (T, U, n) in enumerate(shapes[:3])]
+    _check(pkg, oracle, moved, _run(pkg, moved, blank=b), dict(blank=b))
+    # one text of more than 31 labels in the batch: no narrowing, same answers
+    if V >= 38:
+        wide = segs[:2] + [syn.make_segment(990 + V, 1500, V, 12, 40)]
+        assert len(np.unique(wide[-1][1][1:])) > 32
+        _check(pkg, oracle, wide, _run(pkg, wide))
+
+
+@pytest.mark.parametrize("V", [38, 100, 256])
+def test_narrowed_plan_through_the_plan_api(pkg, oracle, engine, V):
+    """ctcfa_plan_create_shared with the labels and nothing shared: a narrowed plan for device-resident runs, serial and
+    pipelined, against the oracle."""
+    import torch
+    syn = pkg.synthetic
+    B = 24
+    segs = [syn.make_segment(40 + s, 600 + 20 * s, V, 5, 22, alphabet=27) for s in range(B)]
+    T, C, U = [s[0].shape[0] for s in segs], [len(s[1]) for s in segs], [len(s[2]) - 1 for s in segs]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    labels = np.concatenate([s[1] for s in segs]).astype(np.int32)
+    plan = engine.plan(config.to_native(), V, T, C, U, labels=labels)
+    assert plan.info["vocab_pitch"] == 34   # the 32-entry ring
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in segs])).to(dev)
+    d_lab = torch.from_numpy(labels).to(dev)
+    d_ub = torch.from_numpy(np.concatenate([s[2] for s in segs]).astype(np.int32)).to(dev)
+    ocfg = oracle.make_config(index_duration=DUR)
+    ref = [oracle.get_segments(*s, ocfg) for s in segs]
+    co = np.concatenate([[0], np.cumsum(C)])
+    fo = np.concatenate([[0], np.cumsum(T)])
+    for pipelined in (False, True, True):
+        o = dict(fol=torch.zeros(sum(C), dtype=torch.int32, device=dev), cp=torch.zeros(sum(T), dtype=torch.float32, device=dev),
+                 seg=torch.zeros(3, sum(U), dtype=torch.float64, device=dev), te=torch.zeros(B, dtype=torch.int32, device=dev),
+                 status=torch.full((B,), -7, dtype=torch.int32, device=dev))
+        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(), o["cp"].data_ptr(), None,
+                        o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(), o["te"].data_ptr(),
+                        o["status"].data_ptr(), stream, pipelined=pipelined)
+        plan.flush(stream)
+        torch.cuda.synchronize()
+        assert (o["status"].cpu().numpy() == 0).all()
+        fol, cp, te = o["fol"].cpu().numpy(), o["cp"].cpu().numpy(), o["te"].cpu().numpy()
+        for b, r in enumerate(ref):
+            assert te[b] == r["t_end"]
+            assert np.array_equal(fol[co[b]:co[b + 1]], r["frame_of_label"]), b
+            assert np.array_equal(cp[fo[b]:fo[b + 1]].astype(np.float64), r["char_probs"]), b
+    plan.close()
+
+
 def test_nonzero_blank_index(pkg, oracle):
     syn = pkg.synthetic
     segs = [syn.make_segment(300 + s, 300, 32, 3, 20, blank=31) for s in range(4)]
