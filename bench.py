@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--utt-len", type=int, default=28)
     ap.add_argument("--alphabet", type=int, default=0,
                     help="synthetic: the texts use the first N non-blank vocabulary entries only (a character model's vocabulary "
-                         "holds more symbols than its texts show: --vocab 38 --alphabet 28 fills in 150 us where 37 random labels take 176)")
+                         "holds more symbols than its texts show); texts of at most 31 entries beside the blank get a narrowed plan")
     ap.add_argument("--cols-per-lane", type=int, default=int(os.environ.get("CTCFA_K", "0")))
     ap.add_argument("--cpu-sample", type=int, default=512, help="segments timed on the CPU oracle (0 = skip)")
     ap.add_argument("--spinup-steps", type=int, default=1024,
@@ -533,7 +533,11 @@ def main():
     cfg = pkg.CtcSegmentationParameters(index_duration=INDEX_DURATION)
     cfg.backtrack_from_max_t = bool(args.from_max_t)
     eng = pkg._native.Engine(local_rank)
-    plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane)
+    # (a vocabulary above 32 entries whose texts keep to 31 of them -- --vocab 38 --alphabet 28, a character model's windows --
+    # gets a narrowed plan: CTCFA_FLAG_TEXTS_OF_31_LABELS, include/ctcfa.h)
+    promise = V > 32 and all(len(np.unique(g[g != cfg.blank])) <= 32 for h in host_sets for g in h[1])   # (g[0] = -1 counts as one)
+    plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane,
+                    texts_of_31_labels=promise)
     info = plan.info
 
     d_in = [(torch.from_numpy(h[0].reshape(-1)).to(dev), torch.from_numpy(h[1].astype(np.int32).reshape(-1)).to(dev),

@@ -57,11 +57,23 @@ extern "C" {
                                               T <= min_window_size; the other segments of the batch are aligned */
 #define CTCFA_ST_INTERNAL 5                /* a wave of the fill kernel gave up waiting for a progress
                                               counter (bounded spins: a bug must not hang the GPU) */
+#define CTCFA_ST_TOO_MANY_LABELS 6         /* a narrowed plan (CTCFA_FLAG_TEXTS_OF_31_LABELS) met a text that uses more than
+                                              31 vocabulary entries beside the blank; the other segments are aligned */
 
 /* flags (CtcSegmentationParameters.flags + the backtrack switch) */
 #define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; forces checkpoint mode: vocab <= 64, or (ctcfa_align_batch*) <= 63 distinct labels per segment */
 #define CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO 2u /* default of the package         */
 #define CTCFA_FLAG_BACKTRACK_FROM_MAX_T 4u
+/* Not a parameter of the package: the caller's promise that no segment's text uses more than 31 vocabulary entries beside
+ * the blank (a character model's window does: the reference's 38-token model).  A plan for
+ * a vocabulary of 33 .. 256 entries is then NARROWED: trellis fill and backtrack stage the 32 entries each segment looks at
+ * (derived from its labels on the device) and run at the pace of a 32-entry vocabulary -- config 3's shape: 0.155 ms a
+ * pipelined step with 38 entries instead of 0.158, 0.165 with 200 instead of 0.467 -- and blank_transition_cost_zero is
+ * taken above 64 entries.  The results are the un-narrowed plan's.  A segment that breaks the promise gets status
+ * CTCFA_ST_TOO_MANY_LABELS.  Ignored for other vocabularies and for plans with shared fills; entries that get the labels on
+ * the host (ctcfa_align_batch*, ctcfa_plan_create_shared with labels) check them and narrow by themselves.
+ * CTCFA_NO_NARROW=1 in the environment switches narrowing off. */
+#define CTCFA_FLAG_TEXTS_OF_31_LABELS 8u
 
 /* CtcSegmentationParameters fields the DP reads (test_ctc_segmentation.py:20-38 names them). */
 typedef struct ctcfa_params {
@@ -260,10 +272,8 @@ int ctcfa_align_batch_spans(ctcfa_engine* eng, const ctcfa_params* params, int32
  * blocks once).  labels: HOST array of all segments' labels back to back, used to check the prefix
  * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes.
  * With labels given and nothing actually shared (emission_of[b] == b throughout is fine), a vocabulary of 33 .. 256 entries
- * whose segments use at most 31 labels each beside the blank gets a NARROWED plan: the trellis fill runs through the
- * 32-entry kernel on the 32 columns each segment looks at (the reference's 38-token character model: the pace of a 32-entry
- * vocabulary).  The labels of every run of such a plan must be the ones it was created with; the host-buffer entries
- * (ctcfa_align_batch*) narrow by themselves.  CTCFA_NO_NARROW=1 switches it off. */
+ * whose segments use at most 31 labels each beside the blank gets a NARROWED plan (CTCFA_FLAG_TEXTS_OF_31_LABELS, which
+ * asks for one without the labels).  Such a plan serves any later labels that keep to 31 entries per text. */
 int ctcfa_plan_create_shared(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
                              int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
                              const int32_t* emission_of, const int32_t* labels, int32_t force_cols_per_lane);

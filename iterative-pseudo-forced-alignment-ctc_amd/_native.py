@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTCFA_LIB") or os.path.join(_HERE, "csrc", "libctcfa_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, 1, 2, 3, 4
-ST_OK, ST_AUDIO_SHORTER_THAN_TEXT, ST_BACKTRACK_FAILED, ST_WINDOWED_UNSUPPORTED, ST_TEXT_TOO_LONG, ST_INTERNAL = 0, 1, 2, 3, 4, 5
-FLAG_BLANK_TRANSITION_COST_ZERO, FLAG_PREAMBLE_TRANSITION_COST_ZERO, FLAG_BACKTRACK_FROM_MAX_T = 1, 2, 4
+ST_OK, ST_AUDIO_SHORTER_THAN_TEXT, ST_BACKTRACK_FAILED, ST_WINDOWED_UNSUPPORTED, ST_TEXT_TOO_LONG, ST_INTERNAL, ST_TOO_MANY_LABELS = 0, 1, 2, 3, 4, 5, 6
+FLAG_BLANK_TRANSITION_COST_ZERO, FLAG_PREAMBLE_TRANSITION_COST_ZERO, FLAG_BACKTRACK_FROM_MAX_T, FLAG_TEXTS_OF_31_LABELS = 1, 2, 4, 8
 
 # every symbol include/ctcfa.h declares
 EXPORTS = (
@@ -309,25 +309,30 @@ class Engine:
             out.append(d)
         return out
 
-    def plan(self, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None):
-        return Plan(self, params, vocab, T, C, U, force_cols_per_lane, emission_of, labels)
+    def plan(self, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None, texts_of_31_labels=False):
+        return Plan(self, params, vocab, T, C, U, force_cols_per_lane, emission_of, labels, texts_of_31_labels)
 
 
 class Plan:
     """Batch geometry + HBM workspace (``ctcfa_plan``); run it on device-resident buffers."""
 
-    def __init__(self, engine, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None):
+    def __init__(self, engine, params, vocab, T, C, U=None, force_cols_per_lane=0, emission_of=None, labels=None,
+                 texts_of_31_labels=False):
         """emission_of / labels: ``ctcfa_plan_create_shared`` (segments that share emissions; ``labels`` =
-        all segments' labels back to back, for the prefix check and for narrowing, or None)."""
+        all segments' labels back to back, for the prefix check and for narrowing, or None).
+        texts_of_31_labels: CTCFA_FLAG_TEXTS_OF_31_LABELS -- the caller's promise that no text uses more than 31
+        vocabulary entries beside the blank (a narrowed plan for vocabularies of 33 .. 256 entries)."""
         self._eng = engine
         self._lib = engine._lib
         T, C = _i32(T), _i32(C)
         U = _i32(U) if U is not None else None
         h = ctypes.c_void_p()
+        if texts_of_31_labels:
+            params = type(params).from_buffer_copy(params)
+            params.flags |= FLAG_TEXTS_OF_31_LABELS
         if emission_of is None and labels is not None:
             # labels alone: nothing shared, but the plan may look at the texts -- a vocabulary above 32 entries whose
-            # segments use at most 31 labels each runs through the 32-entry fill kernel (a NARROWED plan); the labels of
-            # every later run must then be these
+            # segments use at most 31 labels each gets a NARROWED plan
             emission_of = np.arange(len(T), dtype=np.int32)
         if emission_of is None:
             rc = self._lib.ctcfa_plan_create(engine._h, ctypes.byref(h), ctypes.byref(params), len(T), int(vocab),

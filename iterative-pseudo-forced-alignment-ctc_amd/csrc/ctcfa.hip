@@ -72,8 +72,7 @@ struct ctcfa_plan {
     SegDesc* d_segs = nullptr;
     bool scratch_owned = false;  // d_segs / d_roles / d_bits[0] / d_lastcol[0] live in the engine's scratch
     int VPbt = 0;                       // pitch of the checkpoint-mode backtrack (the vocabulary's own; VP is the FILL's: 32 for a narrowed plan)
-    std::vector<int32_t> narrow;        // narrowed plan: per workgroup (sorted order) 32 + V ints, see ctcfa::fill_kernel
-    int32_t* d_narrow = nullptr;
+    bool narrow = false;                // narrowed plan (ctcfa::narrow_build): fill and backtrack stage the 32 entries each segment's text uses
     // workspaces: index 0 always; the others exist once the pipelined entry has been used
     uint32_t* d_bits[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
     float* d_lastcol[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
@@ -91,7 +90,7 @@ struct ctcfa_plan {
     int ev_stride = 1;       // record timing events on every ev_stride-th run
     int64_t run_counter = 0;
     void (*fill_fn)(const SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int, const int32_t*) = nullptr;
+                    const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int) = nullptr;
     int32_t last_run[kWorkspaces] = {0, 0, 0, 0};   // number of the run that last filled workspace q (its backtrack looks for it in the error word)
     // shared fills: watch columns of every group, the widest group, unique emission frames
     std::vector<ctcfa::WatchDesc> watch;
@@ -208,9 +207,10 @@ int strider_waves(bool lone) {
     return std::max(1, std::min(ctcfa::kSbMaxWaves - 1, n));   // (one more wave may join them as a scorer)
 }
 
-// dynamic LDS of one checkpoint-mode backtrack workgroup: rec | labels | frame_of_label | -inf column + NW slots | char_probs
-int lds_bytes_strider(int rec_bytes, int lab_bytes, int VP, int nw, int T) {
-    return rec_bytes + lab_bytes + 4 * lab_bytes + (nw + 1) * ctcfa::kRows * VP * 4 + T * 4;
+// dynamic LDS of one checkpoint-mode backtrack workgroup: rec | labels | frame_of_label | (a narrowed plan: ring entry ->
+// vocabulary entry, 128 bytes) | -inf column + NW slots | char_probs
+int lds_bytes_strider(int rec_bytes, int lab_bytes, int VP, int nw, int T, bool narrow) {
+    return rec_bytes + lab_bytes + 4 * lab_bytes + (narrow ? 128 : 0) + (nw + 1) * ctcfa::kRows * VP * 4 + T * 4;
 }
 
 // columns a tile of K columns per lane adds to the trellis (its halo lanes are copies)
@@ -452,6 +452,7 @@ const char* ctcfa_status_string(int s) {
         case CTCFA_ST_WINDOWED_UNSUPPORTED: return "windowed DP regime (T > min_window_size) with T beyond the LDS column buffer (~40 000 frames)";
         case CTCFA_ST_TEXT_TOO_LONG: return "more label columns than one workgroup of the fill kernel covers";
         case CTCFA_ST_INTERNAL: return "internal error: a wave of the fill kernel gave up waiting for a progress counter";
+        case CTCFA_ST_TOO_MANY_LABELS: return "the text uses more than 31 vocabulary entries beside the blank (CTCFA_FLAG_TEXTS_OF_31_LABELS promised otherwise)";
         default: return "unknown status";
     }
 }
@@ -533,9 +534,7 @@ void ctcfa_plan_destroy(ctcfa_plan* plan) {
         plan->d_win_list = nullptr;
         plan->d_win_table = nullptr;
         plan->d_win_offs = nullptr;
-        plan->d_narrow = nullptr;
     }
-    if (plan->d_narrow) (void)hipFree(plan->d_narrow);
     if (plan->d_watch) (void)hipFree(plan->d_watch);
     if (plan->d_segs) (void)hipFree(plan->d_segs);
     if (plan->d_roles) (void)hipFree(plan->d_roles);
@@ -606,7 +605,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         "blank_transition_cost_zero needs a vocabulary of at most 64 entries, or a plan created with its labels whose texts use at "
         "most 31 entries each beside the blank (the host-buffer and resident entries also take larger ones whose launch looks at "
         "no more than 63 distinct labels)";
-    if (gratis && vocab > 64 && !(labels && label_width == 1 && vocab <= kMaxStagedVocab))   // (a narrowed plan takes it: decided below)
+    if (gratis && vocab > 64 &&
+        !((labels || (params->flags & CTCFA_FLAG_TEXTS_OF_31_LABELS)) && label_width == 1 && vocab <= kMaxStagedVocab))   // (a narrowed plan takes it: decided below)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, kGratisWide);
     if (params->score_min_mean_over_L < 1 || params->score_min_mean_over_L > kMaxScoreLength)
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, "score_min_mean_over_L must be in [1, 1048576]");
@@ -702,43 +702,44 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             if (members[b]) nwatch_bound = std::max(nwatch_bound, members[b] + 1);
     }
     // Narrowed plan (round 4): a vocabulary of 33 .. 256 entries whose texts -- every segment's own -- use at most 31 of them
-    // beside the blank runs through the 32-ENTRY fill kernel: per segment a table (ring entry -> vocabulary entry, entry 0 the
-    // blank; vocabulary entry -> ring entry), applied by the producers when they stage a row and by the tiles when they look
-    // up their labels.  A character model's window does (the reference's 38-token model; `bench.py --vocab 38 --alphabet 28`);
-    // needs the labels on the host (the host-buffer entries; ctcfa_plan_create_shared with labels) and no shared fills.
-    std::vector<int32_t> narrow_by_b;
-    if (!gather && CTCFA_ADDTID_PRODUCER && label_width == 1 && labels && nwatch_bound == 0 && vocab > 32 && vocab <= kMaxStagedVocab &&
-        params->blank >= 0 && params->blank < vocab && !std::getenv("CTCFA_NO_NARROW")) {
-        const int stride = 32 + vocab;
-        narrow_by_b.assign((size_t)batch * stride, 0);
-        bool ok = true;
-        int64_t o = 0;
-        for (int b = 0; b < batch && ok; o += C[b], ++b) {
-            int32_t* map = narrow_by_b.data() + (size_t)b * stride;
-            int32_t* inv = map + 32;
-            for (int q = 0; q < 32; ++q) map[q] = params->blank;
-            if (pre[b] != CTCFA_ST_OK) continue;
-            int used = 1;   // ring entry 0: the blank
-            std::vector<int8_t> seen(vocab, 0);
-            seen[params->blank] = 1;
-            for (int c = 1; c < C[b]; ++c) {
-                const int32_t g = labels[o + c];
-                if (g < 0 || g >= vocab) { ok = false; break; }   // (such a segment never gets here through the Python mirror; not ours to judge)
-                if (seen[g]) continue;
-                if (used == 32) { ok = false; break; }
-                seen[g] = 1;
-                map[used] = g;
-                inv[g] = used++;
+    // beside the blank runs through the 32-ENTRY fill kernel and the 32-entry checkpoint-mode backtrack: both stage the
+    // entries the segment's text uses (its "ring": ctcfa::narrow_build, derived from the labels on the device by every
+    // workgroup).  A character model's window does (the reference's 38-token model; `bench.py --vocab 38 --alphabet 28`).
+    // Asked for with CTCFA_FLAG_TEXTS_OF_31_LABELS (the caller's promise: a text that breaks it gets status
+    // CTCFA_ST_TOO_MANY_LABELS), or decided here when the labels are at hand (the host-buffer entries;
+    // ctcfa_plan_create_shared with labels); not with shared fills.
+    bool narrowed = false;
+    if (!gather && CTCFA_ADDTID_PRODUCER && label_width == 1 && nwatch_bound == 0 && vocab > 32 && vocab <= kMaxStagedVocab &&
+        !std::getenv("CTCFA_NO_NARROW")) {
+        if (params->flags & CTCFA_FLAG_TEXTS_OF_31_LABELS) {
+            narrowed = true;
+        } else if (labels) {
+            narrowed = true;
+            int64_t o = 0;
+            std::vector<int8_t> seen(vocab);
+            for (int b = 0; b < batch && narrowed; o += C[b], ++b) {
+                if (pre[b] != CTCFA_ST_OK) continue;
+                std::fill(seen.begin(), seen.end(), 0);
+                seen[params->blank] = 1;
+                int used = 0;
+                for (int c = 1; c < C[b] && narrowed; ++c) {
+                    const int32_t g = labels[o + c];
+                    if (g < 0 || g >= vocab) narrowed = false;   // (such a segment never gets here through the Python mirror; not ours to judge)
+                    else if (!seen[g]) {
+                        seen[g] = 1;
+                        narrowed = ++used <= 31;
+                    }
+                }
             }
         }
-        if (!ok) narrow_by_b.clear();
     }
-    if (!narrow_by_b.empty()) {   // fill and checkpoint-mode backtrack stage the table's 32 entries of a row
+    if (narrowed) {
+        pl->narrow = true;
         pl->VP = 32;
         pl->VPbt = 32;
         nprod = 2;
     }
-    if (gratis && vocab > 64 && narrow_by_b.empty()) {
+    if (gratis && vocab > 64 && !narrowed) {
         delete pl;
         return set_err(eng, CTCFA_ERR_UNSUPPORTED, kGratisWide);
     }
@@ -774,14 +775,15 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         // workgroups, with a ring of three slots -- pick_shape: 0.213 ms per pipelined step, 0.240 with round 2's 15.8 KB
         // backtrack, 0.272 with decision words)
         pl->ckpt = can && (std::getenv("CTCFA_CHECKPOINT") ? true : pays) && !std::getenv("CTCFA_DECISION_BITS");
-        if (gratis) pl->ckpt = true;   // (vocab <= 64 checked above)
+        if (gratis) pl->ckpt = true;   // (vocab <= 64 or a narrowed plan: checked above)
+        if (pl->narrow) pl->ckpt = true;   // (the other backtrack does not know the ring: it could not tell a text that breaks the promise)
     }
     // what one backtrack workgroup of this batch will ask for (the exact figure is set further down)
     int bt_lds_estimate;
     {
         const int Tb = Tmax;
         const int rec = ((Tb + ctcfa::kRows - 1) / ctcfa::kRows * 8 + 15) / 16 * 16;
-        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VPbt, strider_waves(batch <= eng->num_cu), Tb) : rec + Tb * 4;
+        bt_lds_estimate = pl->ckpt ? lds_bytes_strider(rec, (Cmax + 15) / 16 * 16, pl->VPbt, strider_waves(batch <= eng->num_cu), Tb, pl->narrow) : rec + Tb * 4;
     }
     ShapeChoice shape{0, 0, 0};
     if (gather) {
@@ -942,9 +944,9 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             pl->bt_waves = strider_waves(batch <= eng->num_cu);
             pl->bt_scorers = (pl->have_utt && !std::getenv("CTCFA_SB_NO_SCORER")) ? 1 : 0;
             pl->fol_bytes = 4 * pl->lab_bytes;
-            pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VPbt, pl->bt_waves, Tbt);
+            pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VPbt, pl->bt_waves, Tbt, pl->narrow);
             while (pl->lds_bt > eng->lds_limit && pl->bt_waves > 1)   // (a very long lone segment: fewer slots rather than no plan)
-                pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VPbt, --pl->bt_waves, Tbt);
+                pl->lds_bt = lds_bytes_strider(pl->rec_bytes, pl->lab_bytes, pl->VPbt, --pl->bt_waves, Tbt, pl->narrow);
         }
     }
     if (pl->lds_bt > eng->lds_limit) {
@@ -968,13 +970,6 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
         for (int i = 0; i < batch; ++i) pos[sorted[i].seg_index] = i;
         for (auto& w : pl->win_list) w = pos[w];   // (windowed_kernel indexes the table through this list)
         pl->segs.swap(sorted);
-    }
-
-    if (!narrow_by_b.empty()) {   // the narrowing tables in the workgroups' (sorted) order
-        const size_t stride = 32 + (size_t)vocab;
-        pl->narrow.resize((size_t)batch * stride);
-        for (int i = 0; i < batch; ++i)
-            std::memcpy(pl->narrow.data() + (size_t)i * stride, narrow_by_b.data() + (size_t)pl->segs[i].seg_index * stride, stride * sizeof(int32_t));
     }
 
 #define PLAN_TRY(expr)                                                                        \
@@ -1006,10 +1001,6 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
             PLAN_TRY(hipMalloc(&pl->d_watch, sizeof(ctcfa::WatchDesc) * pl->watch.size()));
             PLAN_TRY(hipMemcpy(pl->d_watch, pl->watch.data(), sizeof(ctcfa::WatchDesc) * pl->watch.size(), hipMemcpyHostToDevice));
         }
-        if (!pl->narrow.empty()) {
-            PLAN_TRY(hipMalloc(&pl->d_narrow, sizeof(int32_t) * pl->narrow.size()));
-            PLAN_TRY(hipMemcpy(pl->d_narrow, pl->narrow.data(), sizeof(int32_t) * pl->narrow.size(), hipMemcpyHostToDevice));
-        }
     }
     {   // The pipelined entry runs the backtrack of run k beside the fill of run k+1 -- where one fits beside the other.
         // Where not a single backtrack workgroup finds LDS (or registers: the 256-entry kernels take 128, two workgroups
@@ -1027,7 +1018,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_fill));
     if (pl->lds_bt > 48 * 1024)
         PLAN_TRY(hipFuncSetAttribute(!pl->ckpt ? reinterpret_cast<const void*>(ctcfa::backtrack_kernel)
-                                                : reinterpret_cast<const void*>(select_strider(pl->VPbt, !pl->narrow.empty())),
+                                                : reinterpret_cast<const void*>(select_strider(pl->VPbt, pl->narrow)),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pl->lds_bt));
     if (!pl->win_list.empty()) {
         if (use_scratch) {
@@ -1147,14 +1138,14 @@ int launch_fill(ctcfa_plan* pl, const RunArgs& a, int ws, hipStream_t st, hipEve
     hipExtLaunchKernelGGL(pl->fill_fn, dim3(pl->B), dim3(64 * pl->roles.nwaves), pl->lds_fill, st, start, stop, 0,
                           pl->d_segs, a.d_lpz, a.d_labels, pl->d_bits[ws], lastcol_arg, pl->V, pl->prm.blank,
                           ((pl->prm.flags & CTCFA_FLAG_PREAMBLE_TRANSITION_COST_ZERO) ? 1 : 0) |
-                              ((pl->prm.flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) ? 2 : 0),
+                              ((pl->prm.flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) ? 2 : 0) | (pl->narrow ? 4 : 0),
                           (const ctcfa::FillRoles*)pl->d_roles, (const ctcfa::WatchDesc*)pl->d_watch,
 #if defined(CTCFA_STAMP) && CTCFA_STAMP == 4   // the timeline of tools/trace4.py: behind the caller's char_prob buffer (which the tool makes long enough)
                           reinterpret_cast<int32_t*>(a.d_char_prob + (pl->total_T + 1) / 2 * 2),
 #else
                           reinterpret_cast<int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
 #endif
-                          (int)pl->last_run[ws], (const int32_t*)pl->d_narrow);
+                          (int)pl->last_run[ws]);
     HIP_TRY(pl->eng, hipGetLastError());
     return CTCFA_OK;
 }
@@ -1194,7 +1185,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
                            pl->d_lastcol[ws],
                            pl->gather ? nullptr : reinterpret_cast<const int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
                            pl->last_run[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
-                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status, (const int32_t*)pl->d_narrow};
+                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
                               start, (windowed || rescore) ? nullptr : stop, 0, ba);
@@ -1202,7 +1193,7 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         // (the LDS is sized for bt_waves; beside the next batch's fill even a lone launch keeps to three striders:
         // 64 / 128 / 256 segments pipelined 0.1161 / 0.1167 / 0.1178 ms per step with three, 0.1165 / 0.1178 / 0.1190 with seven)
         const int striders = (beside_fill && !std::getenv("CTCFA_SB_WAVES")) ? std::min(pl->bt_waves, 3) : pl->bt_waves;
-        hipExtLaunchKernelGGL(select_strider(pl->VPbt, pl->d_narrow != nullptr), dim3(pl->B), dim3(64 * (striders + pl->bt_scorers)), pl->lds_bt, st,
+        hipExtLaunchKernelGGL(select_strider(pl->VPbt, pl->narrow), dim3(pl->B), dim3(64 * (striders + pl->bt_scorers)), pl->lds_bt, st,
                               start, (windowed || rescore) ? nullptr : stop, 0, ba);
     }
     HIP_TRY(pl->eng, hipGetLastError());
@@ -1531,8 +1522,7 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     const size_t n_watch = pl->watch.size();
     const size_t in_roles = 0, in_segs = up(sizeof(ctcfa::FillRoles)), in_lab = in_segs + up(sizeof(SegDesc) * (size_t)batch),
                  in_ub = in_lab + up(n_lab * 4 * (size_t)pl->S), in_watch = in_ub + (want_seg ? up(n_ub * 4) : 0),
-                 in_narrow = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc)),
-                 in_orig = in_narrow + up(pl->narrow.size() * sizeof(int32_t)),
+                 in_orig = in_watch + up(n_watch * sizeof(ctcfa::WatchDesc)),
                  in_cblk = in_orig + (compact ? up(remap.orig.size() * 4) : 0),
                  in_bytes = in_cblk + (compact ? up(remap.blocks.size() * sizeof(ctcfa::CompactBlock)) : 0);
     const size_t o_fol = 0, o_cp = o_fol + up(n_lab * 4), o_state = o_cp + up(n_frm * 4),
@@ -1560,7 +1550,6 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     std::memcpy(h + in_lab, labels, n_lab * 4 * (size_t)pl->S);
     if (want_seg) std::memcpy(h + in_ub, utt_begin, n_ub * 4);
     if (n_watch) std::memcpy(h + in_watch, pl->watch.data(), n_watch * sizeof(ctcfa::WatchDesc));
-    if (!pl->narrow.empty()) std::memcpy(h + in_narrow, pl->narrow.data(), pl->narrow.size() * sizeof(int32_t));
     if (compact) {
         std::memcpy(h + in_orig, remap.orig.data(), remap.orig.size() * 4);
         std::memcpy(h + in_cblk, remap.blocks.data(), remap.blocks.size() * sizeof(ctcfa::CompactBlock));
@@ -1584,7 +1573,6 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     pl->d_roles = reinterpret_cast<ctcfa::FillRoles*>(d_in + in_roles);
     pl->d_segs = reinterpret_cast<SegDesc*>(d_in + in_segs);
     pl->d_watch = n_watch ? reinterpret_cast<ctcfa::WatchDesc*>(d_in + in_watch) : nullptr;
-    pl->d_narrow = pl->narrow.empty() ? nullptr : reinterpret_cast<int32_t*>(d_in + in_narrow);
     int32_t* d_lab = reinterpret_cast<int32_t*>(d_in + in_lab);
     int32_t* d_ub = want_seg ? reinterpret_cast<int32_t*>(d_in + in_ub) : nullptr;
     double* d_seg = want_seg ? reinterpret_cast<double*>(d_out + o_seg) : nullptr;

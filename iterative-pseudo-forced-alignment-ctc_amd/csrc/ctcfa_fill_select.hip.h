@@ -5,7 +5,7 @@
 #include "ctcfa_kernels.hip.h"
 
 using FillFn = void (*)(const ctcfa::SegDesc*, const float*, const int32_t*, uint32_t*, float*, int, int, int,
-                        const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int, const int32_t*);
+                        const ctcfa::FillRoles*, const ctcfa::WatchDesc*, int32_t*, int);
 
 template <int VP, bool CK>
 FillFn fill_for_k(int K) {

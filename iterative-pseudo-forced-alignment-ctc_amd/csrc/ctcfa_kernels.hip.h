@@ -206,6 +206,78 @@ constexpr int kSpinCap = 1 << 20;     // every wait gives up after ~0.1 s: a los
 #endif
 
 using lds_vint = volatile __attribute__((address_space(3))) int;   // counters in LDS
+
+// ---------------------------------------------------------------------------------------
+// NARROWED plans.  The vocabulary has 33 .. 256 entries, but no segment's text uses more than 31 of them beside the blank
+// (a character model's window: the reference's 38-token model).  Fill and checkpoint-mode backtrack then stage 32 entries of
+// an emission row -- the RING entries of the segment: entry 0 the blank, entry r >= 1 the r-th smallest vocabulary entry its
+// text uses -- and run at the 32-entry pace whatever the vocabulary.  Every wave derives the table from the labels by
+// itself (48 words of LDS that nobody else touches meanwhile, and 256 bytes behind them while it is built; LDS executes a
+// wave's operations in order: no barrier):
+//   [0..7]   the set of vocabulary entries the text uses (the blank left out), a bit each
+//   [8..15]  how many of them lie below each of the eight words
+//   [16..47] ring entry -> vocabulary entry (entries the text leaves free: the blank)
+// A text with more labels than that breaks the caller's promise (CTCFA_FLAG_TEXTS_OF_31_LABELS): the backtrack reports
+// CTCFA_ST_TOO_MANY_LABELS for the segment; the fill keeps every address inside the ring (`& 31`) and its results are dropped.
+// ---------------------------------------------------------------------------------------
+constexpr int kNarrowWords = 48;
+constexpr int kNarrowScratchBytes = kNarrowWords * 4 + 256;   // ... and, while the table is built, a byte per vocabulary entry behind it
+using lds_vuint = volatile __attribute__((address_space(3))) uint32_t;
+using lds_vbyte = volatile __attribute__((address_space(3))) uint8_t;
+__device__ __forceinline__ void narrow_build(lds_vuint* scr, const int32_t* __restrict__ seg_lab, int C, int V, int blank, int lane) {
+    // which entries the text uses: a byte each, set by plain stores (lanes that write the same byte write the same value;
+    // LDS atomics on eight words serialise the 64 lanes of every instruction: ~9 us for config 3's workgroups, all at once)
+    lds_vbyte* used = (lds_vbyte*)(scr + kNarrowWords);
+    scr[kNarrowWords + lane] = 0u;
+    if (lane < 32) scr[16 + lane] = static_cast<uint32_t>(blank);
+    // (sixteen loads in flight: one memory round trip for a text of up to 1 024 labels)
+    for (int c0 = 1; c0 < C; c0 += 64 * 16) {
+        int g[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = c0 + lane + 64 * u;
+            g[u] = seg_lab[c < C ? c : C - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (g[u] != blank) used[g[u] & 255] = 1;
+    }
+    uint32_t word = 0u;   // lanes 0 .. 7: word `lane` of the set
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(used[lane + 64 * i] != 0);
+        if ((lane >> 1) == i) word = (lane & 1) ? static_cast<uint32_t>(m >> 32) : static_cast<uint32_t>(m);
+    }
+    const int cnt = __builtin_popcount(word);
+    int below = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int ci = __builtin_amdgcn_readlane(cnt, i);
+        below += lane > i ? ci : 0;
+    }
+    if (lane < 8) {
+        scr[lane] = word;
+        scr[8 + lane] = static_cast<uint32_t>(below);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = lane + 64 * i;
+        const uint32_t wd = scr[g >> 5];
+        if ((wd >> (g & 31)) & 1u) {
+            const int r = 1 + static_cast<int>(scr[8 + (g >> 5)]) + __builtin_popcount(wd & ((1u << (g & 31)) - 1u));
+            if (r < 32) scr[16 + r] = static_cast<uint32_t>(g < V ? g : V - 1);
+        }
+    }
+}
+// ring entry of vocabulary entry g (anything for an entry the text does not use)
+__device__ __forceinline__ int narrow_rank(lds_vuint* scr, int g, int blank) {
+    const uint32_t word = scr[(g >> 5) & 7];
+    const int r = 1 + static_cast<int>(scr[8 + ((g >> 5) & 7)]) + __builtin_popcount(word & ((1u << (g & 31)) - 1u));
+    return g == blank ? 0 : r;
+}
+__device__ __forceinline__ int narrow_count(lds_vuint* scr) {   // labels beside the blank: at most 31 fit
+    return static_cast<int>(scr[15]) + __builtin_popcount(scr[7]);
+}
 #define CTCFA_SPIN_REPORT() do { if ((threadIdx.x & 63) == 0 && flags[20] != 0) __hip_atomic_store(fill_err, run_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 
 // CTCFA_STAMP=4 (tuning builds): a TIMELINE -- every tile leaves an s_memtime stamp at the end of every 16-row group, the
@@ -282,16 +354,14 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int32_t* __restrict__ labels, uint32_t* __restrict__ bits,
             float* __restrict__ lastcol, int V, int blank, int cost_flags,
             const FillRoles* __restrict__ roles, const WatchDesc* __restrict__ watch,
-            int32_t* __restrict__ fill_err, int run_id, const int32_t* __restrict__ narrow) {
-    // narrow (32-entry pitch only; NULL otherwise): a NARROWED plan -- the vocabulary has more than 32 entries, but no segment's
-    // text uses more than 31 of them beside the blank (a character model's windows: the reference's 38-token model).  Per
-    // workgroup 32 + V ints: ring entry -> vocabulary entry (entry 0 = the blank), vocabulary entry -> ring entry.  The
-    // producers stage the 32 columns a segment looks at, the tiles address the ring by ring entry: the fill runs at the
-    // 32-entry pace whatever the vocabulary; the backtrack works on the emissions themselves and never sees the ring.
+            int32_t* __restrict__ fill_err, int run_id) {
     // cost_flags: bit 0 = preamble_transition_cost_zero (column 0 stays for free), bit 1 =
-    // blank_transition_cost_zero (a column labelled blank stays for free: the blank entry's m is 0)
+    // blank_transition_cost_zero (a column labelled blank stays for free: the blank entry's m is 0), bit 2 (32-entry
+    // pitch only) = a NARROWED plan (see narrow_build): the producers stage the 32 vocabulary entries the segment's
+    // text uses, the tiles address the ring by ring entry
     const bool preamble = (cost_flags & 1) != 0;
     const bool gratis = (cost_flags & 2) != 0;
+    const bool narrowed = VP == 32 && CK && (cost_flags & 4) != 0;   // (narrowed plans run in checkpoint mode)
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool E_ALONE = VP > 80;           // the ring holds e alone (4 B an entry), the tiles work out m: see the producers
     static_assert(!(VP > 64 && CK), "checkpoint mode exists for vocabularies of at most 64 entries");
@@ -318,8 +388,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
     float* __restrict__ seg_lastcol = lastcol + sd.frm_off;
-    const int32_t* __restrict__ nrw = (VP == 32 && narrow) ? narrow + static_cast<int64_t>(blockIdx.x) * (32 + V) : nullptr;
-    const int rblank = nrw ? 0 : blank;   // the blank's entry of the RING
+    const int rblank = narrowed ? 0 : blank;   // the blank's entry of the RING
     const int wn = (K <= kWatchMaxK) ? sd.watch_n : 0;   // watch columns of a shared fill
     const WatchDesc* __restrict__ seg_watch = watch + sd.watch_first;
 
@@ -350,6 +419,28 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         for (int i = tid; i < W * XR * XW; i += blockDim.x) xch[i] = kProbMax;
         if (tid < kFlagInts) flags[tid] = ((tid == 17 && roles->nprod < 2) || tid == 19) ? kBigCount : 0;   // (19: the counter tile 0 "waits" on)
         if (tid < wn) reinterpret_cast<int64_t*>(smem + wtab_base)[tid] = seg_watch[tid].frm_off;
+    }
+    // a narrowed plan: what this wave needs of the segment's table, looked up before the barrier -- the table lies in the
+    // emission ring's first slot, which no producer writes before it
+    int nar_ent = (lane >> 1) < V ? (lane >> 1) : V - 1;   // producers: the vocabulary entry behind ring entry lane >> 1 (fewer than 32 entries: the last one again)
+    int nar_lab[K];            // tiles: the ring entries of this lane's label columns
+#pragma unroll
+    for (int k = 0; k < K; ++k) nar_lab[k] = 0;
+    if (VP == 32 && CK && narrowed) {
+        lds_vuint* scr = (lds_vuint*)(smem + static_cast<uint32_t>(wave_id * kNarrowScratchBytes));
+        int mine[K];   // (asked for before the scan of the text: one memory round trip for both)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = my.cbase + lane * K + k - shift;
+            mine[k] = (my.role != kRoleProducer && c > 0 && c < C) ? seg_lab[c] : blank;
+        }
+        narrow_build(scr, seg_lab, C, V, blank, lane);
+        if (my.role == kRoleProducer) {
+            nar_ent = static_cast<int>(scr[16 + (lane >> 1)]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) nar_lab[k] = narrow_rank(scr, mine[k], blank) & 31;
+        }
     }
     lds_barrier();  // the only workgroup barrier: everything after it is counter-paced
     if (my.role == kRoleIdle) return;
@@ -469,7 +560,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                                           (preamble || !valid) ? 0.0f : __builtin_fmaxf(lb, kProbMax));
             }
         };
-        if (VP == 32 && (V == 32 || nrw != nullptr) && CTCFA_ADDTID_PRODUCER && roles->nprod == 2) {
+        if (VP == 32 && CTCFA_ADDTID_PRODUCER && roles->nprod == 2) {   // 32 entries, fewer (rows of V floats, gathered like a narrowed plan's), or a narrowed plan
             // ---- round 4: the 32-entry vocabulary staged ONE ROW PER STORE.  What the producer costs the tiles is the path its
             // LDS stores share with the loads of its SIMD pair (2 cycles per register dword moved: 13 per ds_write_b128, eight of
             // them per block): ds_write_addtid_b32 has no address register -- the address is M0 + offset + 4 * lane -- and moves
@@ -479,22 +570,40 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // path (8 per row), so two producers share a block: the upper and the lower 16 rows, two register sets each.
             fix_mode = 3;
             constexpr int NR = kRows / 2;
-            const int ent = nrw ? nrw[lane >> 1] : (lane >> 1);   // (a narrowed plan: the vocabulary entry behind ring entry lane >> 1)
+            const int ent = nar_ent;   // (a narrowed plan: the vocabulary entry behind ring entry lane >> 1)
             const bool odd = (lane & 1) != 0;
+            uint32_t noff[8];          // a narrowed plan: byte offsets of this lane's entry in rows 0 .. 7 of a run of rows
+#pragma unroll
+            for (int r = 0; r < 8; ++r) noff[r] = static_cast<uint32_t>(ent + r * V) * 4u;
             // The loads are inline asm and so are the waits for them: left to the compiler, the wait in front of a block's
             // first use was vmcnt(0..3) -- for the loads of the NEXT block too, issued a moment before: a memory round trip in
             // every block of a wave the tiles wait for (trace4: the producer took 2 800 of a block's 3 400 cycles).  vmcnt
             // retires in order: with the next block's NR loads in flight behind them, this block's are there at vmcnt(NR).
             auto aload = [&](int jb, float (&e)[NR]) {
                 const int t0 = jb * kRows + 1 + part * NR;
-                if (V != 32) {   // (a narrowed plan) rows of V entries: the row's address is wave-uniform, an SGPR pair; the lane offset one register
+                if (V != 32) {   // (a narrowed plan, or fewer than 32 entries) rows of V entries: the row's address is wave-uniform, an SGPR pair; the lane offset one register
                     const uint32_t lane_off = static_cast<uint32_t>(ent) * 4u;
+                    if (t0 + NR <= T) {   // (uniform) all 16 rows inside the segment
+                        // No arithmetic between the loads (a producer gets an issue slot every ~20 cycles beside the tiles of its
+                        // SIMD, vector or scalar: a 64-bit row pointer moved on by two scalar adds a row made the 16 loads take
+                        // 800 cycles instead of 550, one vector add a row 1 150): eight lane offsets kept in registers, rows
+                        // r and r + 8 through two row pointers a block.
+                        const float* rowp0 = seg_lpz + static_cast<uint32_t>(t0 * V);
+                        const float* rowp1 = rowp0 + 8 * V;
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        int t = t0 + r;
-                        t = t < T ? t : T - 1;
-                        const float* rowp = seg_lpz + static_cast<uint32_t>(t * V);
-                        asm volatile("global_load_dword %0, %1, %2" : "=v"(e[r]) : "v"(lane_off), "s"(rowp) : "memory");
+                        for (int r = 0; r < 8; ++r)
+                            asm volatile("global_load_dword %0, %1, %2" : "=v"(e[r]) : "v"(noff[r]), "s"(rowp0) : "memory");
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            asm volatile("global_load_dword %0, %1, %2" : "=v"(e[8 + r]) : "v"(noff[r]), "s"(rowp1) : "memory");
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            int t = t0 + r;
+                            t = t < T ? t : T - 1;
+                            const float* rowp = seg_lpz + static_cast<uint32_t>(t * V);
+                            asm volatile("global_load_dword %0, %1, %2" : "=v"(e[r]) : "v"(lane_off), "s"(rowp) : "memory");
+                        }
                     }
                 } else if (t0 + NR <= T) {   // (uniform) all 16 rows inside the segment: one address register, the rows as immediates (V == 32: 128 bytes a row)
                     const uint32_t off = static_cast<uint32_t>(t0 * 32 + ent) * 4u;
@@ -519,17 +628,32 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             auto awrite = [&](int jb, const float (&e)[NR], auto pre_tag) {
                 constexpr bool PRE = decltype(pre_tag)::value;   // preamble_transition_cost_zero (the default): no per-row start-column store
                 const uint32_t rowbase = static_cast<uint32_t>((jb % NS) * SLOT_BYTES + part * NR * ROW_BYTES);   // wave-uniform: M0
+                // eight rows a statement: M0 is set once for them (M0 is reserved: the compiler sets it right before each use of
+                // its own and keeps nothing in it -- between separate statements it may).  A producer gets an issue slot every
+                // ~20 cycles beside the tiles of its SIMD: every instruction less a row is 300 of a block's 3 300 cycles.
+                static_assert(NR == 16, "two halves of eight rows");
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), 2 * rblank));
-                    notneg |= !(e[r] <= 0.0f);
-                    const float m = max3f(lb, e[r], kProbMax);
-                    const float v = odd ? m : e[r];
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2"
-                                 :: "v"(v), "s"(rowbase), "i"(r * ROW_BYTES) : "memory");   // (M0 is reserved: the compiler sets it right before each use of its own and keeps nothing in it)
-                    if (!PRE && lane == 0)   // start-column pseudo entry of the row (under preamble_transition_cost_zero: once, below)
-                        *reinterpret_cast<float2*>(smem + rowbase + static_cast<uint32_t>(r * ROW_BYTES + VP * 8)) =
-                            make_float2(-__builtin_inff(), __builtin_fmaxf(lb, kProbMax));
+                for (int h = 0; h < 2; ++h) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * h + q;
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[r]), 2 * rblank));
+                        notneg |= !(e[r] <= 0.0f);
+                        const float m = max3f(lb, e[r], kProbMax);
+                        v[q] = odd ? m : e[r];
+                        if (!PRE && lane == 0)   // start-column pseudo entry of the row (under preamble_transition_cost_zero: once, below)
+                            *reinterpret_cast<float2*>(smem + rowbase + static_cast<uint32_t>(r * ROW_BYTES + VP * 8)) =
+                                make_float2(-__builtin_inff(), __builtin_fmaxf(lb, kProbMax));
+                    }
+                    asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+                                 "ds_write_addtid_b32 %0 offset:%9+%10*0\n\tds_write_addtid_b32 %1 offset:%9+%10*1\n\t"
+                                 "ds_write_addtid_b32 %2 offset:%9+%10*2\n\tds_write_addtid_b32 %3 offset:%9+%10*3\n\t"
+                                 "ds_write_addtid_b32 %4 offset:%9+%10*4\n\tds_write_addtid_b32 %5 offset:%9+%10*5\n\t"
+                                 "ds_write_addtid_b32 %6 offset:%9+%10*6\n\tds_write_addtid_b32 %7 offset:%9+%10*7"
+                                 :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(rowbase),
+                                    "i"(8 * h * ROW_BYTES), "i"(ROW_BYTES)
+                                 : "memory");
                 }
             };
             if (preamble && part == 0)   // start-column entry (e = -inf, stay step 0) of every row of the ring, once
@@ -917,7 +1041,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
         const int c = pc - shift;
         int lab;
         if (c <= 0) lab = VP;                  // start column / left padding
-        else if (c < C) lab = nrw ? nrw[32 + seg_lab[c]] : seg_lab[c];   // (a narrowed plan: the label's entry of the ring)
+        else if (c < C) lab = narrowed ? nar_lab[k] : seg_lab[c];   // (a narrowed plan: the label's entry of the ring)
         else lab = rblank;                     // right padding: any valid entry
         gaddr[k] = static_cast<uint32_t>(lab) * (E_ALONE ? 4u : 8u);
         startlike[k] = c <= 0;
@@ -1806,7 +1930,6 @@ struct BtArgs {
     double* seg_score;
     int32_t* t_end_out;
     int32_t* status_out;
-    const int32_t* narrow;     // narrowed plan: the fill kernel's per-segment tables (stride_backtrack_kernel<32, true>), else NULL
 };
 
 // NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
@@ -2130,9 +2253,10 @@ __device__ __forceinline__ void for_each_row(F&& f, std::integer_sequence<int, I
     (f(std::integral_constant<int, I>{}), ...);   // rows in order, the row number a compile-time constant
 }
 
-// NARROW (a narrowed plan, P = 32): a staged row holds the 32 vocabulary entries of the segment's table (entry 0 the blank)
-// instead of the whole vocabulary row -- gathered from lpz, four entries of four rows per lane -- and the label bytes are
-// ring entries: the vocabulary itself may have up to 256 entries.
+// NARROW (a narrowed plan, P = 32; see narrow_build): a staged row holds the 32 vocabulary entries of the segment's ring
+// (entry 0 the blank) instead of the whole vocabulary row -- gathered from lpz, four entries of four rows per lane -- and
+// the label bytes are ring entries: the vocabulary itself may have up to 256 entries.  The ring -> vocabulary table (128
+// bytes) lies between frame_of_label and the -inf column.
 template <int P, bool NARROW = false>   // P: LDS row pitch of a staged emission block (the vocabulary rounded up: 32 / 40 / 48 / 56 / 64)
 __global__ void __launch_bounds__(64 * kSbMaxWaves, 5)   // <= 96 VGPRs: room beside the 64-register fill tiles of the next batch
 stride_backtrack_kernel(BtArgs a) {
@@ -2155,7 +2279,6 @@ stride_backtrack_kernel(BtArgs a) {
     const float* __restrict__ seg_lpz = a.lpz + sd.lpz_off;
     const int32_t* __restrict__ seg_lab = a.labels + sd.lab_off;
     const uint32_t* __restrict__ seg_bits = a.bits + sd.bits_off;
-    const int32_t* __restrict__ nrw = NARROW ? a.narrow + (size_t)blockIdx.x * (size_t)(32 + V) : nullptr;
     const int rblank = NARROW ? 0 : p.blank;   // the blank's place in a staged row
     int32_t* fol = a.frame_of_label + sd.lab_off;
     float* cp = a.char_prob + sd.frm_off;
@@ -2179,7 +2302,8 @@ stride_backtrack_kernel(BtArgs a) {
     lds_vint* rec = (lds_vint*)smem;                           // [2j] entry column of block j, [2j+1] its switch mask
     uint8_t* labs = smem + p.rec_bytes;
     int32_t* fol_lds = reinterpret_cast<int32_t*>(smem + p.rec_bytes + p.lab_bytes);   // frame_of_label, for the scoring
-    const uint32_t neg_base = (uint32_t)(p.rec_bytes + p.lab_bytes + p.fol_bytes);
+    lds_vint* nrw = (lds_vint*)(smem + p.rec_bytes + p.lab_bytes + p.fol_bytes);   // NARROW: ring entry -> vocabulary entry
+    const uint32_t neg_base = (uint32_t)(p.rec_bytes + p.lab_bytes + p.fol_bytes + (NARROW ? 128 : 0));
     const uint32_t slot0 = neg_base + SLOT_BYTES;
     float* cps = reinterpret_cast<float*>(smem + slot0 + NW * SLOT_BYTES);   // char_probs of this segment (scoring)
 
@@ -2241,15 +2365,27 @@ stride_backtrack_kernel(BtArgs a) {
         rec[2 * j] = kSbSentinel;
         rec[2 * j + 1] = 0;
     }
+    bool too_many = false;
+    if (NARROW) {   // every wave derives the segment's table by itself, in the slot of the first strider (nothing is staged yet)
+        lds_vuint* scr = (lds_vuint*)(smem + slot0 + (uint32_t)(wave * kNarrowScratchBytes));
+        narrow_build(scr, seg_lab, C, V, p.blank, lane);
+        too_many = narrow_count(scr) > 31;   // (the same answer in every wave)
+        for (int c = tid; c < C; c += nthreads) labs[c] = (uint8_t)(c > 0 ? narrow_rank(scr, seg_lab[c], p.blank) & 31 : 0);
+        if (wave == 0 && lane < 32) nrw[lane] = (int)scr[16 + lane];
+    }
     for (int c = tid; c < C; c += nthreads) {
         fol[c] = 0;
         fol_lds[c] = 0;
-        labs[c] = NARROW ? (uint8_t)nrw[32 + seg_lab[c]] : (uint8_t)seg_lab[c];  // [0] = -1 is never looked up (narrowed: reads table word 31)
+        if (!NARROW) labs[c] = (uint8_t)seg_lab[c];  // [0] = -1 is never looked up
     }
     for (int i = tid; i < kRows * P; i += nthreads) reinterpret_cast<float*>(smem + neg_base)[i] = -__builtin_inff();
     if (tid < 4) sh_misc[tid] = (tid == 3) ? U - 1 : 0;   // [3]: the next utterance to score (from the last one down)
     __threadfence_block();
     __syncthreads();
+    if (NARROW && too_many) {   // (uniform) more than 31 labels beside the blank: the ring cannot hold this text
+        fail(6);                // CTCFA_ST_TOO_MANY_LABELS
+        return;
+    }
 
     int t_end;
     {

@@ -220,6 +220,8 @@ def _raise_for_status(status, error=None):
     if status == _native.ST_TEXT_TOO_LONG:
         raise NotImplementedError("more label columns than one workgroup of the fill kernel covers "
                                   "(ctcfa_max_label_columns: 5 485 for a 32-entry vocabulary, 5 119 for the others up to 256)")
+    if status == _native.ST_TOO_MANY_LABELS:   # (only plans created with texts_of_31_labels: this mirror looks at the labels itself)
+        raise ValueError("the text uses more than 31 vocabulary entries beside the blank in a plan that promised otherwise")
     if status != _native.ST_OK:
         raise RuntimeError(f"ctcfa status {status}")
 

@@ -187,43 +187,102 @@ def test_narrowed_plans(pkg, oracle, V, monkeypatch):
 
 
 @pytest.mark.parametrize("V", [38, 100, 256])
-def test_narrowed_plan_through_the_plan_api(pkg, oracle, engine, V):
-    """ctcfa_plan_create_shared with the labels and nothing shared: a narrowed plan for device-resident runs, serial and
-    pipelined, against the oracle."""
+@pytest.mark.parametrize("how", ["labels", "promise"])
+def test_narrowed_plan_through_the_plan_api(pkg, oracle, engine, V, how):
+    """A narrowed plan for device-resident runs -- created with the labels (ctcfa_plan_create_shared looks at them) or with
+    CTCFA_FLAG_TEXTS_OF_31_LABELS and no labels at all -- serial and pipelined, against the oracle; the same plan then serves
+    OTHER texts of the same geometry (the segments' rings are derived on the device, run by run)."""
     import torch
     syn = pkg.synthetic
     B = 24
-    segs = [syn.make_segment(40 + s, 600 + 20 * s, V, 5, 22, alphabet=27) for s in range(B)]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    ocfg = oracle.make_config(index_duration=DUR)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = None
+    for seed0 in (40, 140):
+        segs = [syn.make_segment(seed0 + s, 600 + 20 * s, V, 5, 22, alphabet=27) for s in range(B)]
+        T, C, U = [s[0].shape[0] for s in segs], [len(s[1]) for s in segs], [len(s[2]) - 1 for s in segs]
+        labels = np.concatenate([s[1] for s in segs]).astype(np.int32)
+        if plan is None:
+            plan = (engine.plan(config.to_native(), V, T, C, U, labels=labels) if how == "labels"
+                    else engine.plan(config.to_native(), V, T, C, U, texts_of_31_labels=True))
+            assert plan.info["vocab_pitch"] == 34   # the 32-entry ring
+        d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in segs])).to(dev)
+        d_lab = torch.from_numpy(labels).to(dev)
+        d_ub = torch.from_numpy(np.concatenate([s[2] for s in segs]).astype(np.int32)).to(dev)
+        ref = [oracle.get_segments(*s, ocfg) for s in segs]
+        co = np.concatenate([[0], np.cumsum(C)])
+        fo = np.concatenate([[0], np.cumsum(T)])
+        for pipelined in (False, True, True):
+            o = dict(fol=torch.zeros(sum(C), dtype=torch.int32, device=dev), cp=torch.zeros(sum(T), dtype=torch.float32, device=dev),
+                     st=torch.zeros(sum(T), dtype=torch.int32, device=dev),
+                     seg=torch.zeros(3, sum(U), dtype=torch.float64, device=dev), te=torch.zeros(B, dtype=torch.int32, device=dev),
+                     status=torch.full((B,), -7, dtype=torch.int32, device=dev))
+            plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(), o["cp"].data_ptr(), o["st"].data_ptr(),
+                            o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(), o["te"].data_ptr(),
+                            o["status"].data_ptr(), stream, pipelined=pipelined)
+            plan.flush(stream)
+            torch.cuda.synchronize()
+            assert (o["status"].cpu().numpy() == 0).all()
+            fol, cp, te, st = o["fol"].cpu().numpy(), o["cp"].cpu().numpy(), o["te"].cpu().numpy(), o["st"].cpu().numpy()
+            for b, r in enumerate(ref):
+                assert te[b] == r["t_end"]
+                assert np.array_equal(fol[co[b]:co[b + 1]], r["frame_of_label"]), b
+                assert np.array_equal(cp[fo[b]:fo[b + 1]].astype(np.float64), r["char_probs"]), b
+                assert np.array_equal(st[fo[b]:fo[b + 1]], r["state"]), b
+    plan.close()
+
+
+def test_narrowed_plan_reports_a_text_of_more_than_31_labels(pkg, oracle, engine):
+    """CTCFA_FLAG_TEXTS_OF_31_LABELS is the caller's promise: a segment whose text breaks it gets status
+    CTCFA_ST_TOO_MANY_LABELS (zeroed outputs), the other segments of the run are aligned -- 31 labels beside the blank fit,
+    32 do not; a blank among the labels does not count."""
+    import torch
+    syn = pkg.synthetic
+    V, n = 64, 120
+    rng = np.random.default_rng(5)
+
+    def text(k):   # n labels over k distinct entries (all of them used), and some blanks
+        g = np.concatenate([np.arange(1, k + 1), rng.integers(1, k + 1, size=n - k - 8), np.zeros(8, np.int64)])
+        rng.shuffle(g)
+        return np.concatenate([[-1], g]).astype(np.int64), np.array([1, 40, 80, n], dtype=np.int64)
+
+    segs = []
+    for s, k in enumerate((31, 32, 12, 40, 31)):
+        gt, ub = text(k)
+        segs.append((syn.make_emissions(np.random.default_rng(900 + s), 700, V, gt, 0), gt, ub))
+    B = len(segs)
     T, C, U = [s[0].shape[0] for s in segs], [len(s[1]) for s in segs], [len(s[2]) - 1 for s in segs]
     config = pkg.CtcSegmentationParameters(index_duration=DUR)
-    labels = np.concatenate([s[1] for s in segs]).astype(np.int32)
-    plan = engine.plan(config.to_native(), V, T, C, U, labels=labels)
-    assert plan.info["vocab_pitch"] == 34   # the 32-entry ring
+    plan = engine.plan(config.to_native(), V, T, C, U, texts_of_31_labels=True)
+    assert plan.info["vocab_pitch"] == 34
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     d_lpz = torch.from_numpy(np.concatenate([s[0].reshape(-1) for s in segs])).to(dev)
-    d_lab = torch.from_numpy(labels).to(dev)
+    d_lab = torch.from_numpy(np.concatenate([s[1] for s in segs]).astype(np.int32)).to(dev)
     d_ub = torch.from_numpy(np.concatenate([s[2] for s in segs]).astype(np.int32)).to(dev)
+    o = dict(fol=torch.full((sum(C),), 9, dtype=torch.int32, device=dev), cp=torch.ones(sum(T), dtype=torch.float32, device=dev),
+             seg=torch.ones(3, sum(U), dtype=torch.float64, device=dev), te=torch.zeros(B, dtype=torch.int32, device=dev),
+             status=torch.full((B,), -7, dtype=torch.int32, device=dev))
+    plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(), o["cp"].data_ptr(), None,
+                    o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(), o["te"].data_ptr(),
+                    o["status"].data_ptr(), stream)
+    torch.cuda.synchronize()
+    status = o["status"].cpu().numpy()
+    assert status.tolist() == [0, pkg._native.ST_TOO_MANY_LABELS, 0, pkg._native.ST_TOO_MANY_LABELS, 0]
     ocfg = oracle.make_config(index_duration=DUR)
-    ref = [oracle.get_segments(*s, ocfg) for s in segs]
     co = np.concatenate([[0], np.cumsum(C)])
-    fo = np.concatenate([[0], np.cumsum(T)])
-    for pipelined in (False, True, True):
-        o = dict(fol=torch.zeros(sum(C), dtype=torch.int32, device=dev), cp=torch.zeros(sum(T), dtype=torch.float32, device=dev),
-                 seg=torch.zeros(3, sum(U), dtype=torch.float64, device=dev), te=torch.zeros(B, dtype=torch.int32, device=dev),
-                 status=torch.full((B,), -7, dtype=torch.int32, device=dev))
-        plan.run_device(d_lpz.data_ptr(), d_lab.data_ptr(), d_ub.data_ptr(), o["fol"].data_ptr(), o["cp"].data_ptr(), None,
-                        o["seg"][0].data_ptr(), o["seg"][1].data_ptr(), o["seg"][2].data_ptr(), o["te"].data_ptr(),
-                        o["status"].data_ptr(), stream, pipelined=pipelined)
-        plan.flush(stream)
-        torch.cuda.synchronize()
-        assert (o["status"].cpu().numpy() == 0).all()
-        fol, cp, te = o["fol"].cpu().numpy(), o["cp"].cpu().numpy(), o["te"].cpu().numpy()
-        for b, r in enumerate(ref):
-            assert te[b] == r["t_end"]
-            assert np.array_equal(fol[co[b]:co[b + 1]], r["frame_of_label"]), b
-            assert np.array_equal(cp[fo[b]:fo[b + 1]].astype(np.float64), r["char_probs"]), b
+    fol, te = o["fol"].cpu().numpy(), o["te"].cpu().numpy()
+    for b, sg in enumerate(segs):
+        if status[b] == 0:
+            r = oracle.get_segments(*sg, ocfg)
+            assert te[b] == r["t_end"] and np.array_equal(fol[co[b]:co[b + 1]], r["frame_of_label"]), b
+        else:
+            assert te[b] == -1 and not fol[co[b]:co[b + 1]].any()
     plan.close()
+    # the host-buffer entry looks at the labels itself: the same batch is simply not narrowed
+    _check(pkg, oracle, segs, _run(pkg, segs))
 
 
 def test_nonzero_blank_index(pkg, oracle):

@@ -30,15 +30,13 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--cols-per-lane", type=int, default=0)
     ap.add_argument("--alphabet", type=int, default=0, help="texts use the first N non-blank entries only")
-    ap.add_argument("--with-labels", action="store_true", help="plans are created with their labels (one plan per input set): vocabularies above 32 entries may get a narrowed plan")
+    ap.add_argument("--narrow", action="store_true", help="plans are created with CTCFA_FLAG_TEXTS_OF_31_LABELS: vocabularies above 32 entries get a narrowed plan")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
     pkg = ge.build()
     syn = pkg.synthetic
     B, T, V, U, n = args.segments, args.frames, args.vocab, args.utts, args.utt_len
-    if args.with_labels:
-        args.sets = 1   # (a plan created with its labels serves those labels only: one input set, so that one plan's events time every step)
     host = [syn.make_uniform_batch(B, T, V, U, n, seed0=64 * k * B, alphabet=args.alphabet or None) for k in range(args.sets)]
     C = host[0][1].shape[1]
     dev = torch.device("cuda:0")
@@ -59,7 +57,7 @@ def main():
             os.environ.update(sets)
             try:
                 plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane,
-                                labels=host[0][1].astype(np.int32).reshape(-1) if args.with_labels else None)
+                                texts_of_31_labels=args.narrow)
             finally:
                 for k, v in old.items():
                     if v is None:

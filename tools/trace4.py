@@ -3,7 +3,8 @@ CTCFA_ALLOW_TUNING_BUILD=1 CTCFA_LIB=variants/trace4.so): s_memtime stamps per t
 arrival at the neighbour poll of group g, [512+g] end of a wait there, [768+j] start of block j -- per producer and block
 ([jb] published, [120+jb] began to look for ring space), for the first 16 workgroups, and each wave's HW_ID.
 Prints, per workgroup: where the waves sit, each tile's pace and what its groups are made of, the lag between neighbours,
-how long the polls waited, the producer's blocks.  usage: trace4.py [K] [B T U n] [--dump file.npz] [--timeline wg]"""
+how long the polls waited, the producer's blocks.  usage: trace4.py [K] [B T U n] [--dump file.npz] [--timeline wg]
+CTCFA_TRACE_V=38: a vocabulary of that many entries, texts over 28 of them, through a narrowed plan."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,14 +26,14 @@ for a in raw:
     argv.append(a)
 K = int(argv[0]) if argv else 0
 syn = pkg.synthetic
-B, T, V, U, n = 512, 3000, 32, 22, 28
+B, T, V, U, n = 512, 3000, int(os.environ.get("CTCFA_TRACE_V", "32")), 22, 28
 if len(argv) > 4:
     B, T, U, n = (int(x) for x in argv[1:5])
-lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n)
+lpz, gt, ub = syn.make_uniform_batch(B, T, V, U, n, alphabet=28 if V > 32 else None)
 C = gt.shape[1]
 cfg = pkg.CtcSegmentationParameters(index_duration=0.02)
 eng = pkg._native.Engine(0)
-plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=K)
+plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=K, texts_of_31_labels=V > 32)
 W = plan.info["waves_per_seg"]
 dev = torch.device("cuda:0")
 d_lpz = torch.from_numpy(lpz.reshape(-1)).to(dev)
