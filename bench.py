@@ -705,6 +705,7 @@ def main():
                        "segments_per_gpu": B, "frames": T, "vocab": V, "label_columns": C,
                        "input_sets": NIN, "input_bytes_resident": int(NIN * B * T * V * 4),
                        "cols_per_lane": info["cols_per_lane"], "waves_per_segment": info["waves_per_seg"],
+                       "narrowed_plan": bool(V > 32 and info["vocab_pitch"] == 34),
                        "parallelism": f"segment-sharded x{world}", "parity": parity,
                        "gather": (f"RCCL all-gather of (start, end, score), one per {G} steps" if do_gather else None),
                        "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
