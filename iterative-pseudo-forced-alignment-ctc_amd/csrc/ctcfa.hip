@@ -107,6 +107,7 @@ struct ctcfa_plan {
     int32_t* d_win_offs = nullptr;
     int64_t win_table_floats = 0, win_cols = 0;
     int lds_win = 0;
+    int win_cmax = 0;   // most label columns of a windowed segment (band_fill_kernel's columns per lane)
     bool gather = false;              // wide vocabulary: fill_gather_kernel
     ctcfa::FillRoles roles{};         // what each wave of a fill workgroup does
     ctcfa::FillRoles* d_roles = nullptr;
@@ -882,7 +883,8 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                 s.win_off = pl->win_table_floats;
                 s.wcol_off = pl->win_cols;
                 pl->win_table_floats += (int64_t)T[b] * C[b];
-                pl->win_cols += C[b];
+                pl->win_cols += C[b] + 2;   // (+ band_fill_kernel's two control words)
+                pl->win_cmax = std::max(pl->win_cmax, (int)C[b]);
                 // T floats at least (char_probs for the scoring); room for two columns of the first
                 // window, or of the whole trellis when that still fits, lets the fill double-buffer
                 {
@@ -1208,6 +1210,21 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.lds_bytes = pl->lds_win;
         wp.S = pl->S;
         wp.dur = pl->prm.index_duration;
+        // single labels: the table by rows first (band_fill_kernel), the walk and the scoring -- and whatever that fill
+        // gives up on -- in windowed_kernel.  CTCFA_NO_BAND_FILL=1: the literal fill only.
+        const int bk = pl->win_cmax <= 1024 ? 1 : pl->win_cmax <= 2048 ? 2 : pl->win_cmax <= 4096 ? 4 : pl->win_cmax <= 8192 ? 8 : 0;
+        const size_t band_lds = (size_t)pl->win_cmax * 8 + 128;
+        wp.prefill = (pl->S == 1 && bk != 0 && band_lds <= (size_t)pl->eng->lds_limit && !std::getenv("CTCFA_NO_BAND_FILL")) ? 1 : 0;
+        if (wp.prefill) {
+            auto fn = bk == 1 ? ctcfa::band_fill_kernel<1> : bk == 2 ? ctcfa::band_fill_kernel<2> : bk == 4 ? ctcfa::band_fill_kernel<4>
+                                                                                                             : ctcfa::band_fill_kernel<8>;
+            if (band_lds > 48 * 1024)
+                HIP_TRY(pl->eng, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
+            hipExtLaunchKernelGGL(fn, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kBandThreads), band_lds, st, nullptr, nullptr, 0,
+                                  (const SegDesc*)pl->d_segs, (const int32_t*)pl->d_win_list, a.d_lpz, a.d_labels, pl->d_win_table,
+                                  pl->d_win_offs, wp);
+            HIP_TRY(pl->eng, hipGetLastError());
+        }
         hipExtLaunchKernelGGL(ctcfa::windowed_kernel, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kWinThreads),
                               pl->lds_win, st, nullptr, rescore ? nullptr : stop, 0, (const SegDesc*)pl->d_segs,
                               (const int32_t*)pl->d_win_list, a.d_lpz, a.d_labels,

@@ -2911,6 +2911,7 @@ struct WinParams {
     int L;
     int min_window, max_window;
     int lds_bytes;  // dynamic LDS given to the kernel
+    int prefill;    // band_fill_kernel ran before this kernel: a window whose control word says so has its table (by absolute frame) and offsets
     int S;          // label width: ground_truth_mat[:, 0..S-1] (tokens of 1..S characters ending in a column); 1 = single labels
     double dur;
 };
@@ -2923,6 +2924,177 @@ __device__ __forceinline__ int64_t np_index(int64_t i, int64_t n, int& err) {
         return 0;
     }
     return i;
+}
+
+// ---------------------------------------------------------------------------------------
+// Windowed regime, the fill done row by row (round 4).  In ABSOLUTE frames the package's windowed table is the plain
+// recurrence restricted to a band: column c lives in frames [O_c, O_c + W), cells outside it count as -1e9 -- and O_c follows
+// from the first maximum of column c - 1 over ITS whole band, which is what makes cython_fill_table sequential column after
+// column (11.8 ns a cell on one lane's dependent chain: 139 ms for a 190 s window).  But the offsets are nearly predictable
+// (0 until the maximum passes the window's middle, then int((T - W) / C) + 1 until T - W is spent), and a table computed
+// under GUESSED offsets proves them: if the offsets derived from its columns' maxima are the guessed ones, then by induction
+// over the columns (column c only looks left) they are the package's.  So: every column at once, a row per step, a lane per
+// K columns (the left neighbour's last value through DPP / an LDS word per wave and a barrier per row) --
+//   pass 0: no band at all (O = 0, W = T), to learn where the columns' maxima lie;
+//   pass p: bands from the offsets derived from pass p - 1; derive again; equal -> done, else once more (each pass gets at
+//           least one more column right; after kBandMaxPasses the literal kernel takes over).
+// The table goes to HBM by absolute frame, row-major [T][C] (coalesced; the walk of windowed_kernel adds the offsets), every
+// pass anew.  Per cell the expressions of windowed_kernel's literal fill, so the bits are the same.
+// Label matrices (S > 1) and windows that double (an IndexError in the walk) stay with the literal fill.
+// workspace control words, behind the window's offsets: [C] 1 = table filled this way for W = min(min_window, T), [C + 1] the
+// last column's first maximum (window row).
+// dynamic LDS: O [C] | first maxima by absolute frame [C] | 2 x 16 exchange words
+// ---------------------------------------------------------------------------------------
+constexpr int kBandThreads = 1024;
+constexpr int kBandMaxPasses = 8;
+
+template <int K>
+__global__ void __launch_bounds__(kBandThreads)
+band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ win_list, const float* __restrict__ lpz,
+                 const int32_t* __restrict__ labels, float* __restrict__ table_ws, int32_t* __restrict__ offs_ws, WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int sh_same;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SegDesc sd = segs[win_list[blockIdx.x]];
+    const int T = sd.T, C = sd.C, V = p.V;
+    const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    float* __restrict__ table = table_ws + sd.win_off;   // [T][C] by absolute frame
+    int32_t* __restrict__ offsets = offs_ws + sd.wcol_off;
+    lds_vint* Ob = (lds_vint*)smem;                       // [C] band starts of the pass
+    lds_vint* amax = Ob + C;                              // [C] first maximum of each column, absolute frame
+    float* xch = reinterpret_cast<float*>(smem + (size_t)C * 8);   // [2][16] last column of every wave, row before
+    const bool preamble = (p.flags & 2u) != 0u;
+    const float pm = kProbMax;
+    const int Wwin = p.min_window < T ? p.min_window : T;
+    const float mean_offset = (float)((double)(T - Wwin) / (double)C);
+    const int higher_offset = (int)mean_offset + 1;
+    constexpr int kBandPF = K >= 8 ? 4 : 8;   // rows of emissions in flight per lane
+    const int c0 = tid * K;
+    int lab[K];
+    bool live[K], free_stay[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = c0 + k;
+        live[k] = c < C;
+        const int g = (live[k] && c > 0) ? seg_lab[c] : -1;
+        lab[k] = g >= 0 ? g : p.blank;   // column 0 (and dead lanes) read the blank entry, unused
+        free_stay[k] = (p.flags & 1u) && g == p.blank;
+    }
+    for (int c = tid; c < C; c += kBandThreads) Ob[c] = 0;
+    if (tid == 0) {
+        offsets[C] = 0;   // not (yet) filled this way
+        offsets[C + 1] = -1;
+    }
+    __syncthreads();
+    bool done = false;
+    for (int pass = 0; pass < kBandMaxPasses && !done; ++pass) {
+        const int W = pass == 0 ? T : Wwin;
+        int O[K], Ol[K];   // band start of the column, and of the column left of it
+        float prev[K], best_v[K];
+        int best_t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = c0 + k;
+            O[k] = live[k] ? Ob[c] : 0;
+            Ol[k] = (live[k] && c > 0) ? Ob[c - 1] : 0;
+            prev[k] = 0.0f;
+            best_v[k] = -__builtin_inff();
+            best_t[k] = 0x7fffffff;
+        }
+        if (lane == 63) xch[wave] = pm, xch[16 + wave] = pm;
+        // emissions: a ring of kBandPF rows in registers
+        float e[kBandPF][K], lb[kBandPF];
+        auto load_row = [&](int tau, int slot) {
+            const int f = tau < T ? tau : T - 1;
+            const float* __restrict__ row = seg_lpz + (int64_t)f * V;
+            lb[slot] = row[p.blank];
+#pragma unroll
+            for (int k = 0; k < K; ++k) e[slot][k] = row[lab[k]];
+        };
+#pragma unroll
+        for (int q = 0; q < kBandPF; ++q) load_row(q, q);
+        __syncthreads();
+        for (int tau0 = 0; tau0 < T; tau0 += kBandPF) {
+#pragma unroll
+            for (int q = 0; q < kBandPF; ++q) {
+                const int tau = tau0 + q;
+                if (tau >= T) break;   // uniform
+                // the column left of this lane's first one, a row ago: the lane before (DPP), the wave before (LDS)
+                float left0 = dpp_wave_shr1(0.0f, prev[K - 1]);
+                if (lane == 0) left0 = wave > 0 ? xch[((tau + 1) & 1) * 16 + wave - 1] : pm;
+                const float lbv = lb[q];
+                float nx[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int c = c0 + k;
+                    const int t = tau - O[k];                       // row of the column's window
+                    const bool inb = (unsigned)t < (unsigned)W;
+                    const float ev = e[q][k];
+                    float b, m;
+                    if (c > 0) {
+                        const float pin = k == 0 ? left0 : prev[k > 0 ? k - 1 : 0];
+                        const bool lin = (unsigned)(tau - 1 - Ol[k]) < (unsigned)W;   // the source cell lies in ITS column's band
+                        const float pcand = lin ? pin + ev : pm;
+                        b = pcand > pm ? pcand : pm;                // switch_prob = max(prob_max, p)
+                        const float mlpz = ev > pm ? ev : pm;
+                        m = mlpz > lbv ? mlpz : lbv;                // max(lpz[blank], max_lpz_prob)
+                        if (free_stay[k]) m = 0.0f;                 // blank_transition_cost_zero
+                    } else {
+                        b = (t == 0) ? 0.0f : pm;                   // table[0, 0] = 0; no switch into column 0
+                        m = preamble ? 0.0f : (pm > lbv ? pm : lbv);
+                    }
+                    if (t == 0) m = -__builtin_inff();              // row 0 has no stay candidate
+                    const float x = __builtin_fmaxf(prev[k] + m, b);
+                    nx[k] = inb ? x : prev[k];
+                    const bool counted = inb && live[k] && !(c == 0 && t == 0);
+                    if (counted && (best_t[k] == 0x7fffffff || x > best_v[k])) {
+                        best_v[k] = x;
+                        best_t[k] = tau;
+                    }
+                    if (inb && live[k]) table[(int64_t)tau * C + c] = x;
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) prev[k] = nx[k];
+                if (lane == 63) xch[(tau & 1) * 16 + wave] = prev[K - 1];
+                load_row(tau + kBandPF, q);   // (the slot just used)
+                lds_barrier();   // (orders the exchange words only: __syncthreads would wait for the loads just issued)
+            }
+        }
+        // the offsets these maxima lead to
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (live[k]) amax[c0 + k] = best_t[k] == 0x7fffffff ? -1 : best_t[k];
+        __syncthreads();
+        if (tid == 0) {
+            int same = pass > 0;
+            int sum = 0;
+            for (int c = 1; c < C; ++c) {
+                const int am = amax[c - 1];
+                int a = (am < 0 ? -1 : am - sum) - Wwin / 2;        // lastArgMax of column c - 1 is a row of ITS window
+                if (a < 0) a = 0;
+                int b = (T - Wwin) - sum;
+                if (higher_offset < b) b = higher_offset;
+                sum += a < b ? a : b;
+                same &= Ob[c] == sum;
+                Ob[c] = sum;
+            }
+            sh_same = same;
+        }
+        __syncthreads();
+        done = sh_same != 0;
+    }
+    if (done) {
+        for (int c = tid; c < C; c += kBandThreads) offsets[c] = Ob[c];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            offsets[C + 1] = amax[C - 1] < 0 ? -1 : amax[C - 1] - Ob[C - 1];
+            offsets[C] = 1;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kWinThreads)
@@ -2976,6 +3148,10 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
         // every chunk) and waves 1..3 copy the finished column to the table while the next one is
         // being computed.  Otherwise one buffer, updated in place, and wave 0 stores itself.
         const bool dbl = (int64_t)W * 8 <= (int64_t)p.lds_bytes;
+        // the first attempt of a single-label window: band_fill_kernel has filled the table (row-major by ABSOLUTE frame) and
+        // the offsets, if its control word says so
+        const bool pre = p.prefill && S == 1 && window == (long long)p.min_window &&
+                         __hip_atomic_load(offsets + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
         // ------------------------------- fill ------------------------------------------
         const float mean_offset = (float)((double)(T - W) / (double)C);
         const int higher_offset = (int)mean_offset + 1;
@@ -2984,7 +3160,8 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
 #pragma unroll
         for (int q = 0; q < kMaxSpan; ++q) cur_off[q] = -1;
         const int nchunk = (W + 63) / 64;
-        for (int c = 0; c < C; ++c) {
+        if (pre) last_arg = __hip_atomic_load(offsets + C + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = 0; c < (pre ? 0 : C); ++c) {
             float* colw = col + ((dbl && (c & 1)) ? W : 0);         // this column
             const float* colr = col + ((dbl && !(c & 1)) ? W : 0);  // previous column
             if (wave == 0) {
@@ -3146,11 +3323,12 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
             int err = 0;
             int te = (p.flags & 4u) ? W - 1 : last_arg;
             if (lane == 0) {
-                auto tab = [&](int64_t r, int64_t cc) -> float {
-                    return __hip_atomic_load(table + cc * W + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
                 auto offs = [&](int64_t cc) -> int64_t {
                     return (int64_t)__hip_atomic_load(offsets + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                auto tab = [&](int64_t r, int64_t cc) -> float {   // table[r, cc], r a row of column cc's window
+                    const int64_t at = pre ? (r + offs(cc)) * C + cc : cc * W + r;
+                    return __hip_atomic_load(table + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 };
                 const double max_prob = -10000000000.0;
                 int64_t t = te, c = C - 1, offset = 0;
