@@ -1210,11 +1210,13 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.lds_bytes = pl->lds_win;
         wp.S = pl->S;
         wp.dur = pl->prm.index_duration;
+        wp.fast_walk = std::getenv("CTCFA_NO_FAST_WALK") ? 0 : 1;
         // single labels: the table by rows first (band_fill_kernel), the walk and the scoring -- and whatever that fill
         // gives up on -- in windowed_kernel.  CTCFA_NO_BAND_FILL=1: the literal fill only.
         const int bk = pl->win_cmax <= 1024 ? 1 : pl->win_cmax <= 2048 ? 2 : pl->win_cmax <= 4096 ? 4 : pl->win_cmax <= 8192 ? 8 : 0;
-        const size_t band_lds = (size_t)pl->win_cmax * 8 + 128;
-        wp.prefill = (pl->S == 1 && bk != 0 && band_lds <= (size_t)pl->eng->lds_limit && !std::getenv("CTCFA_NO_BAND_FILL")) ? 1 : 0;
+        const size_t band_lds = (size_t)ctcfa::band_lds_bytes(pl->win_cmax, pl->V);
+        wp.prefill = (pl->S == 1 && bk != 0 && pl->V <= ctcfa::kBandThreads && band_lds <= (size_t)pl->eng->lds_limit &&
+                      !std::getenv("CTCFA_NO_BAND_FILL")) ? 1 : 0;
         if (wp.prefill) {
             auto fn = bk == 1 ? ctcfa::band_fill_kernel<1> : bk == 2 ? ctcfa::band_fill_kernel<2> : bk == 4 ? ctcfa::band_fill_kernel<4>
                                                                                                              : ctcfa::band_fill_kernel<8>;

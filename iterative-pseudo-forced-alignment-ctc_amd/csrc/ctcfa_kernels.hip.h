@@ -2911,6 +2911,7 @@ struct WinParams {
     int L;
     int min_window, max_window;
     int lds_bytes;  // dynamic LDS given to the kernel
+    int fast_walk;  // single labels: 64 steps of the walk at a time where the cells are plain (0: the literal step only)
     int prefill;    // band_fill_kernel ran before this kernel: a window whose control word says so has its table (by absolute frame) and offsets
     int S;          // label width: ground_truth_mat[:, 0..S-1] (tokens of 1..S characters ending in a column); 1 = single labels
     double dur;
@@ -2943,10 +2944,15 @@ __device__ __forceinline__ int64_t np_index(int64_t i, int64_t n, int& err) {
 // Label matrices (S > 1) and windows that double (an IndexError in the walk) stay with the literal fill.
 // workspace control words, behind the window's offsets: [C] 1 = table filled this way for W = min(min_window, T), [C + 1] the
 // last column's first maximum (window row).
-// dynamic LDS: O [C] | first maxima by absolute frame [C] | 2 x 16 exchange words
+// dynamic LDS: O [C] | first maxima by absolute frame [C] | 2 x 16 exchange words | kBandSlots emission rows
 // ---------------------------------------------------------------------------------------
 constexpr int kBandThreads = 1024;
 constexpr int kBandMaxPasses = 8;
+constexpr int kBandPF = 8;      // emission rows in flight (registers of the lanes that stage them)
+constexpr int kBandSlots = 4;   // staged emission rows in LDS: row tau + 2 is written while row tau is computed
+__host__ __device__ constexpr int band_lds_bytes(int C, int V) { return C * 8 + 2 * 16 * 4 + kBandSlots * V * 4; }
+
+struct __attribute__((packed, aligned(4))) F2U { float x, y; };   // two consecutive floats, dword aligned
 
 template <int K>
 __global__ void __launch_bounds__(kBandThreads)
@@ -2966,12 +2972,12 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
     lds_vint* Ob = (lds_vint*)smem;                       // [C] band starts of the pass
     lds_vint* amax = Ob + C;                              // [C] first maximum of each column, absolute frame
     float* xch = reinterpret_cast<float*>(smem + (size_t)C * 8);   // [2][16] last column of every wave, row before
+    float* stage = xch + 32;                              // [kBandSlots][V] emission rows
     const bool preamble = (p.flags & 2u) != 0u;
     const float pm = kProbMax;
     const int Wwin = p.min_window < T ? p.min_window : T;
     const float mean_offset = (float)((double)(T - Wwin) / (double)C);
     const int higher_offset = (int)mean_offset + 1;
-    constexpr int kBandPF = K >= 8 ? 4 : 8;   // rows of emissions in flight per lane
     const int c0 = tid * K;
     int lab[K];
     bool live[K], free_stay[K];
@@ -2989,9 +2995,17 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
         offsets[C + 1] = -1;
     }
     __syncthreads();
+    // Emission rows reach the lanes through LDS: lane v < V of the workgroup loads entry v of row tau + 2 + kBandPF while row
+    // tau is computed and writes the one that has arrived (row tau + 2) to the ring -- ONE load instruction a row and wave
+    // instead of K + 1 gathers per lane, which kept the CU's one texture unit busy for ~800 cycles a row.
+    auto row_entry = [&](int tau) -> float {
+        const int f = tau < T ? tau : T - 1;
+        return seg_lpz[(int64_t)f * V + (tid < V ? tid : 0)];
+    };
     bool done = false;
     for (int pass = 0; pass < kBandMaxPasses && !done; ++pass) {
         const int W = pass == 0 ? T : Wwin;
+        const bool keep = pass > 0;   // (pass 0 has no band: its table is nobody's)
         int O[K], Ol[K];   // band start of the column, and of the column left of it
         float prev[K], best_v[K];
         int best_t[K];
@@ -3005,18 +3019,18 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
             best_t[k] = 0x7fffffff;
         }
         if (lane == 63) xch[wave] = pm, xch[16 + wave] = pm;
-        // emissions: a ring of kBandPF rows in registers
-        float e[kBandPF][K], lb[kBandPF];
-        auto load_row = [&](int tau, int slot) {
-            const int f = tau < T ? tau : T - 1;
-            const float* __restrict__ row = seg_lpz + (int64_t)f * V;
-            lb[slot] = row[p.blank];
+        if (tid < V) {
+            stage[0 * V + tid] = row_entry(0);
+            stage[1 * V + tid] = row_entry(1);
+        }
+        float ering[kBandPF];   // rows tau + 2 .. tau + 1 + kBandPF of this lane's entry, on their way
 #pragma unroll
-            for (int k = 0; k < K; ++k) e[slot][k] = row[lab[k]];
-        };
-#pragma unroll
-        for (int q = 0; q < kBandPF; ++q) load_row(q, q);
+        for (int q = 0; q < kBandPF; ++q) ering[q] = row_entry(2 + q);
         __syncthreads();
+        float ev[K], lbv;   // row tau's operands, read from the ring a row ahead
+        lbv = stage[p.blank];
+#pragma unroll
+        for (int k = 0; k < K; ++k) ev[k] = stage[lab[k]];
         for (int tau0 = 0; tau0 < T; tau0 += kBandPF) {
 #pragma unroll
             for (int q = 0; q < kBandPF; ++q) {
@@ -3025,21 +3039,25 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
                 // the column left of this lane's first one, a row ago: the lane before (DPP), the wave before (LDS)
                 float left0 = dpp_wave_shr1(0.0f, prev[K - 1]);
                 if (lane == 0) left0 = wave > 0 ? xch[((tau + 1) & 1) * 16 + wave - 1] : pm;
-                const float lbv = lb[q];
+                // next row's operands (staged a row ago; the barrier at the end of that row made them visible)
+                const float* nrow = stage + ((tau + 1) & (kBandSlots - 1)) * V;
+                const float lb_next = nrow[p.blank];
+                float ev_next[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) ev_next[k] = nrow[lab[k]];
                 float nx[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int c = c0 + k;
                     const int t = tau - O[k];                       // row of the column's window
                     const bool inb = (unsigned)t < (unsigned)W;
-                    const float ev = e[q][k];
                     float b, m;
                     if (c > 0) {
                         const float pin = k == 0 ? left0 : prev[k > 0 ? k - 1 : 0];
                         const bool lin = (unsigned)(tau - 1 - Ol[k]) < (unsigned)W;   // the source cell lies in ITS column's band
-                        const float pcand = lin ? pin + ev : pm;
+                        const float pcand = lin ? pin + ev[k] : pm;
                         b = pcand > pm ? pcand : pm;                // switch_prob = max(prob_max, p)
-                        const float mlpz = ev > pm ? ev : pm;
+                        const float mlpz = ev[k] > pm ? ev[k] : pm;
                         m = mlpz > lbv ? mlpz : lbv;                // max(lpz[blank], max_lpz_prob)
                         if (free_stay[k]) m = 0.0f;                 // blank_transition_cost_zero
                     } else {
@@ -3054,13 +3072,30 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
                         best_v[k] = x;
                         best_t[k] = tau;
                     }
-                    if (inb && live[k]) table[(int64_t)tau * C + c] = x;
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) prev[k] = nx[k];
                 if (lane == 63) xch[(tau & 1) * 16 + wave] = prev[K - 1];
-                load_row(tau + kBandPF, q);   // (the slot just used)
-                lds_barrier();   // (orders the exchange words only: __syncthreads would wait for the loads just issued)
+                if (keep) {   // cells outside a column's band are written too (what the lane holds): nobody reads them
+                    float* out = table + (int64_t)tau * C + c0;
+                    if constexpr (K % 2 == 0) {
+#pragma unroll
+                        for (int k = 0; k < K; k += 2) {
+                            if (live[k + 1]) *reinterpret_cast<F2U*>(out + k) = F2U{prev[k], prev[k + 1]};
+                            else if (live[k]) out[k] = prev[k];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            if (live[k]) out[k] = prev[k];
+                    }
+                }
+                if (tid < V) stage[((tau + 2) & (kBandSlots - 1)) * V + tid] = ering[q];
+                ering[q] = row_entry(tau + 2 + kBandPF);
+                lbv = lb_next;
+#pragma unroll
+                for (int k = 0; k < K; ++k) ev[k] = ev_next[k];
+                lds_barrier();   // (orders LDS traffic only: __syncthreads would wait for the loads just issued)
             }
         }
         // the offsets these maxima lead to
@@ -3319,107 +3354,201 @@ windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ wi
         __threadfence();
         __syncthreads();
         if (wave == 0) {
-            // ------------------------------- walk (lane 0) ---------------------------------
+            // ------------------------------- walk -----------------------------------------
+            // The package's loop, a step at a time, on lane 0 (`literal_step`) -- and, for plain labels away from the table's
+            // edges, 64 steps at once: lane l looks at the cell l frames further back in the SAME column (as if the path had
+            // stayed l times), every lane works out the package's two residuals from the same table entries and emissions
+            // with the same fp32 operations, and the first lane that says SWITCH ends the run: the lanes before it are the
+            // path's stays, it is the switch, the walk goes on one column to the left.  ~C + T / 64 rounds of loads instead of
+            // T + C.  A lane whose cell is not plain (an index that would wrap or raise, a
+            // residual that is not a number, an emission at or below max_prob) stops the run in front of it; if that is lane
+            // 0 the literal step takes it.
             int err = 0;
             int te = (p.flags & 4u) ? W - 1 : last_arg;
-            if (lane == 0) {
-                auto offs = [&](int64_t cc) -> int64_t {
-                    return (int64_t)__hip_atomic_load(offsets + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
-                auto tab = [&](int64_t r, int64_t cc) -> float {   // table[r, cc], r a row of column cc's window
-                    const int64_t at = pre ? (r + offs(cc)) * C + cc : cc * W + r;
-                    return __hip_atomic_load(table + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
-                const double max_prob = -10000000000.0;
-                int64_t t = te, c = C - 1, offset = 0;
-                while ((t != 0 || c != 0) && !err) {
-                    int min_s = -1;
-                    double min_delta = __builtin_inf();
-                    double max_lpz = max_prob;
-                    bool max_lpz_f32 = false;
-                    const int64_t cw = np_index(c, C, err);
+            auto offs = [&](int64_t cc) -> int64_t {
+                return (int64_t)__hip_atomic_load(offsets + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            auto tab = [&](int64_t r, int64_t cc) -> float {   // table[r, cc], r a row of column cc's window
+                const int64_t at = pre ? (r + offs(cc)) * C + cc : cc * W + r;
+                return __hip_atomic_load(table + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            const double max_prob = -10000000000.0;
+            int64_t t = te, c = C - 1, offset = 0;   // (wave-uniform)
+            auto literal_step = [&]() {
+                int min_s = -1;
+                double min_delta = __builtin_inf();
+                double max_lpz = max_prob;
+                bool max_lpz_f32 = false;
+                const int64_t cw = np_index(c, C, err);
+                if (err) return;
+                int g = -1;   // ground_truth[c, min_s]
+                for (int sp = 0; sp < S && !err; ++sp) {
+                    const int gs = seg_lab[cw * S + sp];
+                    if (gs == -1) continue;
+                    const int64_t pc = np_index(c - 1 - sp, C, err);
                     if (err) break;
-                    int g = -1;   // ground_truth[c, min_s]
-                    for (int sp = 0; sp < S && !err; ++sp) {
-                        const int gs = seg_lab[cw * S + sp];
-                        if (gs == -1) continue;
-                        const int64_t pc = np_index(c - 1 - sp, C, err);
-                        if (err) break;
-                        offset = offs(cw) - ((c - sp > 0) ? offs(pc) : 0);   // (the last s looked at leaves its value behind, as in the package)
-                        double sp_prob;
-                        bool sp_f32 = false;
-                        if (c > 0) {
-                            const int64_t r = np_index(t + offs(cw), T, err);
-                            const int64_t gi = np_index(gs, V, err);
-                            if (err) break;
-                            sp_prob = (double)seg_lpz[r * V + gi];
-                            sp_f32 = true;
-                        } else {
-                            sp_prob = max_prob;
-                        }
-                        const int64_t r0 = np_index(t, W, err);
-                        const int64_t r1 = np_index(t - 1 + offset, W, err);
-                        if (err) break;
-                        const float est32 = tab(r0, cw) - tab(r1, pc);
-                        double delta;
-                        if (sp_f32) delta = (double)__builtin_fabsf((float)sp_prob - est32);
-                        else delta = __builtin_fabs(sp_prob - (double)est32);
-                        if (delta < min_delta) {
-                            min_delta = delta;
-                            min_s = sp;
-                            g = gs;
-                        }
-                        if (sp_prob > max_lpz) {
-                            max_lpz = sp_prob;
-                            max_lpz_f32 = sp_f32;
-                        }
-                    }
-                    if (err) break;
-                    double stay;
-                    bool stay_f32 = false;
-                    if (t > 0) {
+                    offset = offs(cw) - ((c - sp > 0) ? offs(pc) : 0);   // (the last s looked at leaves its value behind, as in the package)
+                    double sp_prob;
+                    bool sp_f32 = false;
+                    if (c > 0) {
                         const int64_t r = np_index(t + offs(cw), T, err);
+                        const int64_t gi = np_index(gs, V, err);
                         if (err) break;
-                        const double lb = (double)seg_lpz[r * V + p.blank];
-                        if (max_lpz > lb) {
-                            stay = max_lpz;
-                            stay_f32 = max_lpz_f32;
-                        } else {
-                            stay = lb;
-                            stay_f32 = true;
-                        }
+                        sp_prob = (double)seg_lpz[r * V + gi];
+                        sp_f32 = true;
                     } else {
-                        stay = max_prob;
+                        sp_prob = max_prob;
                     }
                     const int64_t r0 = np_index(t, W, err);
-                    const int64_t r1 = np_index(t - 1, W, err);
+                    const int64_t r1 = np_index(t - 1 + offset, W, err);
                     if (err) break;
-                    const float est_stay32 = tab(r0, cw) - tab(r1, cw);
-                    double stay_delta;
-                    if (stay_f32) stay_delta = (double)__builtin_fabsf((float)stay - est_stay32);
-                    else stay_delta = __builtin_fabs(stay - (double)est_stay32);
-                    if (stay_delta > min_delta) {
-                        if (c > 0) {
-                            const int64_t fr = np_index(offs(cw) + t, T, err);
-                            if (err) break;
-                            for (int sp = 0; sp <= min_s && !err; ++sp) {   // every character of the token
-                                const int64_t ci = np_index(c - sp, C, err);
-                                if (!err) fol[ci] = (int32_t)(offs(cw) + t);
-                            }
-                            if (err) break;
-                            cp[fr] = (float)max_lpz;
-                            if (st) st[fr] = g;
-                        }
-                        c -= 1 + min_s;
-                        t -= 1 - offset;
-                    } else {
-                        const int64_t fr = np_index(offs(cw) + t, T, err);
-                        if (err) break;
-                        cp[fr] = (float)stay;
-                        if (st) st[fr] = -1;
-                        t -= 1;
+                    const float est32 = tab(r0, cw) - tab(r1, pc);
+                    double delta;
+                    if (sp_f32) delta = (double)__builtin_fabsf((float)sp_prob - est32);
+                    else delta = __builtin_fabs(sp_prob - (double)est32);
+                    if (delta < min_delta) {
+                        min_delta = delta;
+                        min_s = sp;
+                        g = gs;
+                    }
+                    if (sp_prob > max_lpz) {
+                        max_lpz = sp_prob;
+                        max_lpz_f32 = sp_f32;
                     }
                 }
+                if (err) return;
+                double stay;
+                bool stay_f32 = false;
+                if (t > 0) {
+                    const int64_t r = np_index(t + offs(cw), T, err);
+                    if (err) return;
+                    const double lb = (double)seg_lpz[r * V + p.blank];
+                    if (max_lpz > lb) {
+                        stay = max_lpz;
+                        stay_f32 = max_lpz_f32;
+                    } else {
+                        stay = lb;
+                        stay_f32 = true;
+                    }
+                } else {
+                    stay = max_prob;
+                }
+                const int64_t r0 = np_index(t, W, err);
+                const int64_t r1 = np_index(t - 1, W, err);
+                if (err) return;
+                const float est_stay32 = tab(r0, cw) - tab(r1, cw);
+                double stay_delta;
+                if (stay_f32) stay_delta = (double)__builtin_fabsf((float)stay - est_stay32);
+                else stay_delta = __builtin_fabs(stay - (double)est_stay32);
+                if (stay_delta > min_delta) {
+                    if (c > 0) {
+                        const int64_t fr = np_index(offs(cw) + t, T, err);
+                        if (err) return;
+                        for (int sp = 0; sp <= min_s && !err; ++sp) {   // every character of the token
+                            const int64_t ci = np_index(c - sp, C, err);
+                            if (!err) fol[ci] = (int32_t)(offs(cw) + t);
+                        }
+                        if (err) return;
+                        cp[fr] = (float)max_lpz;
+                        if (st) st[fr] = g;
+                    }
+                    c -= 1 + min_s;
+                    t -= 1 - offset;
+                } else {
+                    const int64_t fr = np_index(offs(cw) + t, T, err);
+                    if (err) return;
+                    cp[fr] = (float)stay;
+                    if (st) st[fr] = -1;
+                    t -= 1;
+                }
+            };
+            int have_c = -1, have_Oc = 0, have_Op = 0;   // offsets of columns have_c and have_c - 1, loaded a round earlier
+            // lanes that look ahead: 16 (a path stays T / C frames in a column, 7.6 in a 190 s window; every lane asks for two
+            // table rows and an emission row of its own -- 64 lanes are 200 cache lines a round, ~10 us of one CU's misses),
+            // all 64 after a round that met no switch (a long stay: silence)
+            int ahead = 16;
+            while ((t != 0 || c != 0) && !err) {
+                bool taken = false;
+                if (S == 1 && p.fast_walk && c >= 1 && t >= 1) {
+                    const int Oc = have_c == (int)c ? have_Oc : (int)offs(c);
+                    const int Op = have_c == (int)c ? have_Op : (int)offs(c - 1);
+                    const int Onext = c >= 2 ? (int)offs(c - 2) : 0;   // (on its way while this round's cells are)
+                    const int off = Oc - Op;
+                    const int tl = (int)t - lane;
+                    const int g = seg_lab[c];
+                    const int64_t fr = (int64_t)tl + Oc;
+                    bool reg = lane < ahead && tl >= 1 && tl < W && tl - 1 + off < W && fr < T && g >= 0 && g < V;
+                    float spv = 0.0f, stay = 0.0f;
+                    bool sw = false;
+                    if (reg) {
+                        // table[tl, c], table[tl - 1 + off, c - 1], table[tl - 1, c]: by absolute frame the two rows fr, fr - 1
+                        auto cell = [&](int64_t r, int64_t cc, int64_t Occ) -> float {
+                            const int64_t at = pre ? (r + Occ) * C + cc : cc * W + r;
+                            return __hip_atomic_load(table + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        };
+                        const float a = cell(tl, c, Oc), bl = cell(tl - 1 + off, c - 1, Op), d = cell(tl - 1, c, Oc);
+                        spv = seg_lpz[fr * V + g];
+                        const float lbv = seg_lpz[fr * V + p.blank];
+                        const float delta = __builtin_fabsf(spv - (a - bl));          // fp32 - fp32, fp32 residual
+                        stay = spv > lbv ? spv : lbv;                                  // max(lpz[blank], max_lpz_prob)
+                        const float stay_delta = __builtin_fabsf(stay - (a - d));
+                        reg = spv > -10000000000.0f && delta < __builtin_inff() && stay_delta == stay_delta;
+                        sw = stay_delta > delta;
+                    }
+                    const unsigned long long bad = __builtin_amdgcn_ballot_w64(!reg);
+                    const unsigned long long swm = __builtin_amdgcn_ballot_w64(reg && sw);
+                    const int nreg = bad ? __builtin_ctzll(bad) : 64;
+                    const int lsw = swm ? __builtin_ctzll(swm) : 64;
+                    if (nreg > 0) {
+                        taken = true;
+                        const bool hit = lsw < nreg;
+                        const int nst = hit ? lsw : nreg;   // lanes 0 .. nst - 1 are stays
+                        if (lane < nst) {
+                            cp[fr] = stay;
+                            if (st) st[fr] = -1;
+                        } else if (hit && lane == lsw) {
+                            fol[c] = (int32_t)fr;
+                            cp[fr] = spv;
+                            if (st) st[fr] = g;
+                        }
+                        if (hit) {
+                            t = t - lsw - 1 + off;
+                            c -= 1;
+                            offset = off;
+                            have_c = (int)c;
+                            have_Oc = Op;
+                            have_Op = Onext;
+                            ahead = 16;
+                        } else {
+                            ahead = 64;
+                            t -= nreg;
+                            have_c = (int)c;
+                            have_Oc = Oc;
+                            have_Op = Op;
+                        }
+                    }
+                }
+                if (S == 1 && p.fast_walk && !taken && c == 0 && t >= 1 && t < W && t < T && seg_lab[0] == -1) {
+                    // The start column (no label: the package's loop over s finds nothing, min_delta stays inf and the step
+                    // is a stay whatever the table holds) down to frame 0, every frame at once: char_probs = max(blank
+                    // posterior, max_prob) in the package's order of comparison.  offsets[0] == 0.
+                    for (int tt = (int)t - lane; tt >= 1; tt -= 64) {
+                        const float lbv = seg_lpz[(int64_t)tt * V + p.blank];
+                        cp[tt] = (-10000000000.0 > (double)lbv) ? -10000000000.0f : lbv;
+                        if (st) st[tt] = -1;
+                    }
+                    t = 0;
+                    taken = true;
+                }
+                if (!taken) {
+                    if (lane == 0) literal_step();
+                    t = __builtin_amdgcn_readfirstlane((int)t);
+                    c = __builtin_amdgcn_readfirstlane((int)c);
+                    offset = __builtin_amdgcn_readfirstlane((int)offset);
+                    err = __builtin_amdgcn_readfirstlane(err);
+                }
+            }
+            if (lane == 0) {
                 sh_res[0] = te;
                 sh_res[1] = err;
             }

@@ -718,6 +718,62 @@ def test_windowed_regime_noisy_and_flat_emissions(pkg, oracle):
         _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
 
 
+@pytest.mark.parametrize("paths", ["rows+wave", "rows+literal", "literal+wave", "literal+literal"])
+def test_windowed_regime_fill_and_walk_paths_agree(pkg, oracle, monkeypatch, paths):
+    """The windowed regime has two fills (band_fill_kernel: row by row under guessed offsets that the result proves; the
+    literal column-by-column one) and two walks (64 steps at a time on plain cells; the literal step): every combination
+    gives the oracle's results -- planted paths, noise, flat rows, vocabularies that are not 32 entries, every flag, texts
+    of more than 1 024 / 2 048 label columns (two / four columns per lane), emissions that hold NaN and infinities."""
+    fill, walk = paths.split("+")
+    if fill == "literal":
+        monkeypatch.setenv("CTCFA_NO_BAND_FILL", "1")
+    if walk == "literal":
+        monkeypatch.setenv("CTCFA_NO_FAST_WALK", "1")
+    syn = pkg.synthetic
+    for seed, T, U, n, mw in _windowed_cases():
+        seg = syn.make_segment(seed, T, 32, U, n)
+        kw = dict(min_window_size=mw, max_window_size=1000)
+        _check(pkg, oracle, [seg], _run(pkg, [seg], **kw), cfg_kw=kw)
+    # noise and flat rows, other vocabularies, the flags
+    segs = []
+    for s in range(6):
+        rng = np.random.default_rng(2100 + s)
+        V = (32, 29, 38, 76, 200, 5)[s]
+        gt, ub = syn.make_labels(rng, 5 + s, 10, V)
+        T = 500 + 120 * s
+        lpz = (np.log(rng.dirichlet(np.ones(V) * (0.3 if s % 2 else 5.0), size=T)).astype(np.float32) if s < 4
+               else syn.make_emissions(rng, T, V, gt))
+        segs.append((lpz, gt, ub, V))
+    for lpz, gt, ub, V in segs:
+        for kw in (dict(min_window_size=64, max_window_size=4000), dict(min_window_size=150, max_window_size=4000, backtrack_from_max_t=True),
+                   dict(min_window_size=100, max_window_size=4000, preamble_transition_cost_zero=False)):
+            _check(pkg, oracle, [(lpz, gt, ub)], _run(pkg, [(lpz, gt, ub)], **kw), cfg_kw=kw)
+    # long texts: more than one column per lane of the row-by-row fill
+    for seed, T, U, n, mw in ((2200, 2600, 60, 20, 1500), (2201, 4500, 110, 20, 3000)):
+        seg = syn.make_segment(seed, T, 32, U, n)
+        kw = dict(min_window_size=mw, max_window_size=100000)
+        _check(pkg, oracle, [seg], _run(pkg, [seg], **kw), cfg_kw=kw)
+    # emissions that are not numbers
+    rng = np.random.default_rng(2300)
+    for k in range(6):
+        lpz, gt, ub = syn.make_segment(2300 + k, 700, 32, 8, 12)
+        lpz = lpz.copy()
+        rows = rng.integers(1, 700, size=5)
+        cols = rng.integers(0, 32, size=5)
+        lpz[rows, cols] = (np.nan, np.inf, -np.inf, np.nan, 3.0e38)[k % 5]
+        if k == 5:
+            lpz[rng.integers(1, 700, size=3), 0] = np.nan   # the blank itself
+        kw = dict(min_window_size=200, max_window_size=3000)
+        r = _run(pkg, [(lpz, gt, ub)], **kw)[0]
+        o = oracle.get_segments(lpz, gt, ub, oracle.make_config(index_duration=DUR, **kw))
+        assert r["status"] == o["status"], k
+        if o["status"] == 0:
+            assert r["t_end"] == o["t_end"], k
+            assert np.array_equal(r["frame_of_label"], o["frame_of_label"]), k
+            assert np.array_equal(r["char_prob"].astype(np.float64), o["char_probs"], equal_nan=True), k
+            assert np.array_equal(r["state"], o["state"]), k
+
+
 def test_windowed_regime_production_window(pkg, oracle):
     """The package defaults (min_window_size=8000): a 190 s window, T = 9500 frames."""
     seg = pkg.synthetic.make_segment(1950, 9500, 32, 40, 30)
