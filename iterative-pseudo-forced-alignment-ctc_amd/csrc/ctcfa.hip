@@ -1222,7 +1222,9 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
                                                                                                              : ctcfa::band_fill_kernel<8>;
             if (band_lds > 48 * 1024)
                 HIP_TRY(pl->eng, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
-            hipExtLaunchKernelGGL(fn, dim3((unsigned)pl->win_list.size()), dim3(ctcfa::kBandThreads), band_lds, st, nullptr, nullptr, 0,
+            // (whole waves for the widest window's columns, and at least V lanes: they stage the emission rows)
+            const int band_threads = std::min(ctcfa::kBandThreads, std::max(((pl->win_cmax + bk - 1) / bk + 63) / 64 * 64, (pl->V + 63) / 64 * 64));
+            hipExtLaunchKernelGGL(fn, dim3((unsigned)pl->win_list.size()), dim3(band_threads), band_lds, st, nullptr, nullptr, 0,
                                   (const SegDesc*)pl->d_segs, (const int32_t*)pl->d_win_list, a.d_lpz, a.d_labels, pl->d_win_table,
                                   pl->d_win_offs, wp);
             HIP_TRY(pl->eng, hipGetLastError());

@@ -2936,9 +2936,9 @@ __device__ __forceinline__ int64_t np_index(int64_t i, int64_t n, int& err) {
 // under GUESSED offsets proves them: if the offsets derived from its columns' maxima are the guessed ones, then by induction
 // over the columns (column c only looks left) they are the package's.  So: every column at once, a row per step, a lane per
 // K columns (the left neighbour's last value through DPP / an LDS word per wave and a barrier per row) --
-//   pass 0: no band at all (O = 0, W = T), to learn where the columns' maxima lie;
-//   pass p: bands from the offsets derived from pass p - 1; derive again; equal -> done, else once more (each pass gets at
-//           least one more column right; after kBandMaxPasses the literal kernel takes over).
+//   pass 0: bands from a first guess (the higher offset from column 2 on until T - W is spent);
+//   pass p: bands from the offsets derived from pass p - 1's maxima; derive again; equal -> done, else once more (each pass
+//           gets at least one more column right; after kBandMaxPasses the literal kernel takes over).
 // The table goes to HBM by absolute frame, row-major [T][C] (coalesced; the walk of windowed_kernel adds the offsets), every
 // pass anew.  Per cell the expressions of windowed_kernel's literal fill, so the bits are the same.
 // Label matrices (S > 1) and windows that double (an IndexError in the walk) stay with the literal fill.
@@ -2961,6 +2961,7 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int sh_same;
     const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;   // the widest window's columns / K, in whole waves (and at least V lanes: they stage the rows)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SegDesc sd = segs[win_list[blockIdx.x]];
@@ -2974,115 +2975,134 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
     float* xch = reinterpret_cast<float*>(smem + (size_t)C * 8);   // [2][16] last column of every wave, row before
     float* stage = xch + 32;                              // [kBandSlots][V] emission rows
     const bool preamble = (p.flags & 2u) != 0u;
+    const bool gratis = (p.flags & 1u) != 0u;
     const float pm = kProbMax;
+    const float ninf = -__builtin_inff();
     const int Wwin = p.min_window < T ? p.min_window : T;
     const float mean_offset = (float)((double)(T - Wwin) / (double)C);
     const int higher_offset = (int)mean_offset + 1;
     const int c0 = tid * K;
-    int lab[K];
+    const bool wave_live = (wave * 64 + 63) * K + K <= C;   // every column of this wave exists: stores need no masks
+    const bool stager = wave * 64 < V;                      // this wave holds entries of the emission rows on their way to LDS
+    uint32_t laddr[K];   // byte offset of the column's label in a staged row
     bool live[K], free_stay[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = c0 + k;
         live[k] = c < C;
         const int g = (live[k] && c > 0) ? seg_lab[c] : -1;
-        lab[k] = g >= 0 ? g : p.blank;   // column 0 (and dead lanes) read the blank entry, unused
-        free_stay[k] = (p.flags & 1u) && g == p.blank;
+        laddr[k] = (uint32_t)(g >= 0 ? g : p.blank) * 4u;   // column 0 (and dead lanes) read the blank entry, unused
+        free_stay[k] = gratis && g == p.blank;
     }
-    for (int c = tid; c < C; c += kBandThreads) Ob[c] = 0;
     if (tid == 0) {
         offsets[C] = 0;   // not (yet) filled this way
         offsets[C + 1] = -1;
+        // the first guess: column 0's first maximum is its row 1 under preamble_transition_cost_zero (a column of zeros), so
+        // column 1 starts with it; from there on every column's maximum taken to lie past the window's middle -- the higher
+        // offset until T - W is spent.  (Right or wrong, a pass derives the next guess from what it computed.)
+        int sum = 0;
+        Ob[0] = 0;
+        for (int c = 1; c < C; ++c) {
+            int b = (T - Wwin) - sum;
+            if (higher_offset < b) b = higher_offset;
+            if (c >= 2) sum += b;
+            Ob[c] = sum;
+        }
     }
     __syncthreads();
     // Emission rows reach the lanes through LDS: lane v < V of the workgroup loads entry v of row tau + 2 + kBandPF while row
-    // tau is computed and writes the one that has arrived (row tau + 2) to the ring -- ONE load instruction a row and wave
-    // instead of K + 1 gathers per lane, which kept the CU's one texture unit busy for ~800 cycles a row.
+    // tau is computed and writes the one that has arrived (row tau + 2) to the ring -- ONE load instruction a row and staging
+    // wave instead of K + 1 gathers per lane.
     auto row_entry = [&](int tau) -> float {
         const int f = tau < T ? tau : T - 1;
         return seg_lpz[(int64_t)f * V + (tid < V ? tid : 0)];
     };
     bool done = false;
     for (int pass = 0; pass < kBandMaxPasses && !done; ++pass) {
-        const int W = pass == 0 ? T : Wwin;
-        const bool keep = pass > 0;   // (pass 0 has no band: its table is nobody's)
-        int O[K], Ol[K];   // band start of the column, and of the column left of it
+        const int W = Wwin;
+        // A cell outside its column's band is held as -inf: whatever is added to it loses against the -1e9 floor of the
+        // switch candidate and against the switch candidate itself, which is exactly what the package's range checks make of
+        // it (the row before a band's first one: no stay candidate; a source cell outside the left column's band: p = -1e9)
+        // -- the row loop carries ONE test per cell, "inside the band".
+        int O[K];
         float prev[K], best_v[K];
         int best_t[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int c = c0 + k;
-            O[k] = live[k] ? Ob[c] : 0;
-            Ol[k] = (live[k] && c > 0) ? Ob[c - 1] : 0;
-            prev[k] = 0.0f;
-            best_v[k] = -__builtin_inff();
-            best_t[k] = 0x7fffffff;
+            O[k] = live[k] ? Ob[c0 + k] : 0;
+            prev[k] = ninf;
+            best_v[k] = ninf;   // (a cell inside a band is >= -1e9 and never NaN: the first one always counts)
+            best_t[k] = -1;
         }
-        if (lane == 63) xch[wave] = pm, xch[16 + wave] = pm;
+        if (lane == 63) xch[wave] = ninf, xch[16 + wave] = ninf;
         if (tid < V) {
             stage[0 * V + tid] = row_entry(0);
             stage[1 * V + tid] = row_entry(1);
         }
         float ering[kBandPF];   // rows tau + 2 .. tau + 1 + kBandPF of this lane's entry, on their way
 #pragma unroll
-        for (int q = 0; q < kBandPF; ++q) ering[q] = row_entry(2 + q);
+        for (int q = 0; q < kBandPF; ++q) ering[q] = stager ? row_entry(2 + q) : 0.0f;
         __syncthreads();
+        const unsigned char* stage_b = reinterpret_cast<const unsigned char*>(stage);
         float ev[K], lbv;   // row tau's operands, read from the ring a row ahead
         lbv = stage[p.blank];
 #pragma unroll
-        for (int k = 0; k < K; ++k) ev[k] = stage[lab[k]];
+        for (int k = 0; k < K; ++k) ev[k] = *reinterpret_cast<const float*>(stage_b + laddr[k]);
         for (int tau0 = 0; tau0 < T; tau0 += kBandPF) {
 #pragma unroll
             for (int q = 0; q < kBandPF; ++q) {
                 const int tau = tau0 + q;
                 if (tau >= T) break;   // uniform
                 // the column left of this lane's first one, a row ago: the lane before (DPP), the wave before (LDS)
-                float left0 = dpp_wave_shr1(0.0f, prev[K - 1]);
-                if (lane == 0) left0 = wave > 0 ? xch[((tau + 1) & 1) * 16 + wave - 1] : pm;
+                float left0 = dpp_wave_shr1(ninf, prev[K - 1]);
+                if (wave > 0 && lane == 0) left0 = xch[((tau + 1) & 1) * 16 + wave - 1];
                 // next row's operands (staged a row ago; the barrier at the end of that row made them visible)
-                const float* nrow = stage + ((tau + 1) & (kBandSlots - 1)) * V;
-                const float lb_next = nrow[p.blank];
+                const unsigned char* nrow = stage_b + (uint32_t)(((tau + 1) & (kBandSlots - 1)) * V * 4);
+                const float lb_next = *reinterpret_cast<const float*>(nrow + p.blank * 4);
                 float ev_next[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) ev_next[k] = nrow[lab[k]];
+                for (int k = 0; k < K; ++k) ev_next[k] = *reinterpret_cast<const float*>(nrow + laddr[k]);
                 float nx[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const int c = c0 + k;
-                    const int t = tau - O[k];                       // row of the column's window
-                    const bool inb = (unsigned)t < (unsigned)W;
-                    float b, m;
-                    if (c > 0) {
-                        const float pin = k == 0 ? left0 : prev[k > 0 ? k - 1 : 0];
-                        const bool lin = (unsigned)(tau - 1 - Ol[k]) < (unsigned)W;   // the source cell lies in ITS column's band
-                        const float pcand = lin ? pin + ev[k] : pm;
-                        b = pcand > pm ? pcand : pm;                // switch_prob = max(prob_max, p)
-                        const float mlpz = ev[k] > pm ? ev[k] : pm;
-                        m = mlpz > lbv ? mlpz : lbv;                // max(lpz[blank], max_lpz_prob)
-                        if (free_stay[k]) m = 0.0f;                 // blank_transition_cost_zero
-                    } else {
-                        b = (t == 0) ? 0.0f : pm;                   // table[0, 0] = 0; no switch into column 0
-                        m = preamble ? 0.0f : (pm > lbv ? pm : lbv);
-                    }
-                    if (t == 0) m = -__builtin_inff();              // row 0 has no stay candidate
-                    const float x = __builtin_fmaxf(prev[k] + m, b);
-                    nx[k] = inb ? x : prev[k];
-                    const bool counted = inb && live[k] && !(c == 0 && t == 0);
-                    if (counted && (best_t[k] == 0x7fffffff || x > best_v[k])) {
-                        best_v[k] = x;
-                        best_t[k] = tau;
-                    }
+                    const float pin = k == 0 ? left0 : prev[k > 0 ? k - 1 : 0];
+                    const float b = __builtin_fmaxf(pin + ev[k], pm);   // switch_prob = max(prob_max, p)
+                    const float mlpz = __builtin_fmaxf(ev[k], pm);      // max_lpz_prob
+                    float m = mlpz > lbv ? mlpz : lbv;                  // max(lpz[blank], max_lpz_prob), the package's order
+                    if (gratis) m = free_stay[k] ? 0.0f : m;            // blank_transition_cost_zero
+                    nx[k] = __builtin_fmaxf(prev[k] + m, b);
+                }
+                if (wave == 0) {   // column 0: no switch into it (table[0, 0] = 0), its own stay step
+                    const float m0 = preamble ? 0.0f : (pm > lbv ? pm : lbv);
+                    const float x0 = __builtin_fmaxf(prev[0] + m0, tau == 0 ? 0.0f : pm);
+                    nx[0] = tid == 0 ? x0 : nx[0];
                 }
 #pragma unroll
-                for (int k = 0; k < K; ++k) prev[k] = nx[k];
+                for (int k = 0; k < K; ++k) {
+                    const bool inb = (unsigned)(tau - O[k]) < (unsigned)W;
+                    const float x = inb ? nx[k] : ninf;
+                    prev[k] = x;
+                    const bool up = x > best_v[k];   // (first maximum: strict)
+                    best_v[k] = up ? x : best_v[k];
+                    best_t[k] = up ? tau : best_t[k];
+                }
+                if (tau == 0 && tid == 0) {   // the package's loop over column 0 starts at row 1
+                    best_v[0] = ninf;
+                    best_t[0] = -1;
+                }
                 if (lane == 63) xch[(tau & 1) * 16 + wave] = prev[K - 1];
-                if (keep) {   // cells outside a column's band are written too (what the lane holds): nobody reads them
+                {   // (cells outside a band go out as -inf: nobody reads them)
                     float* out = table + (int64_t)tau * C + c0;
-                    if constexpr (K % 2 == 0) {
+                    if (wave_live) {
+                        if constexpr (K % 4 == 0) {
 #pragma unroll
-                        for (int k = 0; k < K; k += 2) {
-                            if (live[k + 1]) *reinterpret_cast<F2U*>(out + k) = F2U{prev[k], prev[k + 1]};
-                            else if (live[k]) out[k] = prev[k];
+                            for (int k = 0; k < K; k += 4) *reinterpret_cast<F4U*>(out + k) = F4U{prev[k], prev[k + 1], prev[k + 2], prev[k + 3]};
+                        } else if constexpr (K % 2 == 0) {
+#pragma unroll
+                            for (int k = 0; k < K; k += 2) *reinterpret_cast<F2U*>(out + k) = F2U{prev[k], prev[k + 1]};
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) out[k] = prev[k];
                         }
                     } else {
 #pragma unroll
@@ -3090,8 +3110,10 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
                             if (live[k]) out[k] = prev[k];
                     }
                 }
-                if (tid < V) stage[((tau + 2) & (kBandSlots - 1)) * V + tid] = ering[q];
-                ering[q] = row_entry(tau + 2 + kBandPF);
+                if (stager) {
+                    if (tid < V) stage[((tau + 2) & (kBandSlots - 1)) * V + tid] = ering[q];
+                    ering[q] = row_entry(tau + 2 + kBandPF);
+                }
                 lbv = lb_next;
 #pragma unroll
                 for (int k = 0; k < K; ++k) ev[k] = ev_next[k];
@@ -3101,10 +3123,10 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
         // the offsets these maxima lead to
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if (live[k]) amax[c0 + k] = best_t[k] == 0x7fffffff ? -1 : best_t[k];
+            if (live[k]) amax[c0 + k] = best_t[k];
         __syncthreads();
         if (tid == 0) {
-            int same = pass > 0;
+            int same = 1;
             int sum = 0;
             for (int c = 1; c < C; ++c) {
                 const int am = amax[c - 1];
@@ -3122,7 +3144,7 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
         done = sh_same != 0;
     }
     if (done) {
-        for (int c = tid; c < C; c += kBandThreads) offsets[c] = Ob[c];
+        for (int c = tid; c < C; c += nthreads) offsets[c] = Ob[c];
         __threadfence();
         __syncthreads();
         if (tid == 0) {
