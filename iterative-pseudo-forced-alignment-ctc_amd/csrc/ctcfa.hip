@@ -1213,17 +1213,27 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
         wp.fast_walk = std::getenv("CTCFA_NO_FAST_WALK") ? 0 : 1;
         // single labels: the table by rows first (band_fill_kernel), the walk and the scoring -- and whatever that fill
         // gives up on -- in windowed_kernel.  CTCFA_NO_BAND_FILL=1: the literal fill only.
-        const int bk = pl->win_cmax <= 1024 ? 1 : pl->win_cmax <= 2048 ? 2 : pl->win_cmax <= 4096 ? 4 : pl->win_cmax <= 8192 ? 8 : 0;
-        const size_t band_lds = (size_t)ctcfa::band_lds_bytes(pl->win_cmax, pl->V);
+        // (vocabularies of at most 256 entries: a barrier every 16 rows -- band_fill_halo_kernel; CTCFA_BAND_ROW_BARRIER=1 or a
+        // wider vocabulary: a barrier a row)
+        int hk = 0;
+        for (int k : {1, 2, 4})   // (eight columns per lane spill in the 16-row block loop: 144 ms against 132 for 25 000 x 6 002)
+            if (!hk && (pl->win_cmax + ctcfa::band_halo_own_cols(k) - 1) / ctcfa::band_halo_own_cols(k) <= 16) hk = k;
+        const size_t halo_lds = (size_t)ctcfa::band_halo_lds_bytes(pl->win_cmax, pl->V);
+        const bool halo = hk != 0 && pl->V <= 256 && halo_lds <= (size_t)pl->eng->lds_limit && !std::getenv("CTCFA_BAND_ROW_BARRIER");
+        const int bk = halo ? hk : pl->win_cmax <= 1024 ? 1 : pl->win_cmax <= 2048 ? 2 : pl->win_cmax <= 4096 ? 4 : pl->win_cmax <= 8192 ? 8 : 0;
+        const size_t band_lds = halo ? halo_lds : (size_t)ctcfa::band_lds_bytes(pl->win_cmax, pl->V);
         wp.prefill = (pl->S == 1 && bk != 0 && pl->V <= ctcfa::kBandThreads && band_lds <= (size_t)pl->eng->lds_limit &&
                       !std::getenv("CTCFA_NO_BAND_FILL")) ? 1 : 0;
         if (wp.prefill) {
-            auto fn = bk == 1 ? ctcfa::band_fill_kernel<1> : bk == 2 ? ctcfa::band_fill_kernel<2> : bk == 4 ? ctcfa::band_fill_kernel<4>
-                                                                                                             : ctcfa::band_fill_kernel<8>;
+            auto fn = halo ? (bk == 1 ? ctcfa::band_fill_halo_kernel<1> : bk == 2 ? ctcfa::band_fill_halo_kernel<2>
+                                       : bk == 4 ? ctcfa::band_fill_halo_kernel<4> : ctcfa::band_fill_halo_kernel<8>)
+                           : (bk == 1 ? ctcfa::band_fill_kernel<1> : bk == 2 ? ctcfa::band_fill_kernel<2>
+                                       : bk == 4 ? ctcfa::band_fill_kernel<4> : ctcfa::band_fill_kernel<8>);
             if (band_lds > 48 * 1024)
                 HIP_TRY(pl->eng, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
             // (whole waves for the widest window's columns, and at least V lanes: they stage the emission rows)
-            const int band_threads = std::min(ctcfa::kBandThreads, std::max(((pl->win_cmax + bk - 1) / bk + 63) / 64 * 64, (pl->V + 63) / 64 * 64));
+            const int per_wave = halo ? ctcfa::band_halo_own_cols(bk) : 64 * bk;
+            const int band_threads = std::min(ctcfa::kBandThreads, std::max((pl->win_cmax + per_wave - 1) / per_wave * 64, (pl->V + 63) / 64 * 64));
             hipExtLaunchKernelGGL(fn, dim3((unsigned)pl->win_list.size()), dim3(band_threads), band_lds, st, nullptr, nullptr, 0,
                                   (const SegDesc*)pl->d_segs, (const int32_t*)pl->d_win_list, a.d_lpz, a.d_labels, pl->d_win_table,
                                   pl->d_win_offs, wp);

@@ -3154,6 +3154,234 @@ band_fill_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ w
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// band_fill_halo_kernel: the same fill with a workgroup barrier every kBandRows rows instead of every row (vocabularies of
+// at most 256 entries).  As in fill_kernel, the first HL = kBandRows / K lanes of a wave are a HALO -- copies of the wave
+// before's last kBandRows columns, wrong by one more column per row (their own left neighbour is missing), set right from
+// an LDS exchange area every kBandRows rows; a wave's own columns never see the error.  Emission rows come in blocks of
+// kBandRows: the first V lanes load a block ahead into registers and write it to the other half of a two-block LDS ring
+// before the barrier.  56 of 64 lanes carry columns of their own (K = 2): 12 waves for a window of 1 242 columns, and the
+// row loop runs at the pace of its instructions (~450 cycles a row) instead of the barrier's (~880).
+// dynamic LDS: O [C] | first maxima [C] | 2 x 16 x kBandRows exchange floats | 2 x kBandRows emission rows
+// ---------------------------------------------------------------------------------------
+constexpr int kBandRows = 16;
+__host__ __device__ constexpr int band_halo_lds_bytes(int C, int V) { return C * 8 + 2 * 16 * kBandRows * 4 + 2 * kBandRows * V * 4; }
+__host__ __device__ constexpr int band_halo_own_cols(int K) { return (64 - kBandRows / K) * K; }   // columns of its own per wave
+
+template <int K>
+__global__ void __launch_bounds__(kBandThreads)
+band_fill_halo_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ win_list, const float* __restrict__ lpz,
+                      const int32_t* __restrict__ labels, float* __restrict__ table_ws, int32_t* __restrict__ offs_ws, WinParams p) {
+    static_assert(kBandRows % K == 0, "a halo is a whole number of lanes");
+    constexpr int R = kBandRows;
+    constexpr int HL = R / K;             // halo lanes
+    constexpr int U = (64 - HL) * K;      // columns of its own per wave
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int sh_same;
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SegDesc sd = segs[win_list[blockIdx.x]];
+    const int T = sd.T, C = sd.C, V = p.V;
+    const float* __restrict__ seg_lpz = lpz + sd.lpz_off;
+    const int32_t* __restrict__ seg_lab = labels + sd.lab_off;
+    float* __restrict__ table = table_ws + sd.win_off;   // [T][C] by absolute frame
+    int32_t* __restrict__ offsets = offs_ws + sd.wcol_off;
+    lds_vint* Ob = (lds_vint*)smem;
+    lds_vint* amax = Ob + C;
+    float* xch = reinterpret_cast<float*>(smem + (size_t)C * 8);   // [2][16][R]: the last R columns of every wave at a block's end
+    float* stage = xch + 2 * 16 * R;                               // [2][R][V] emission rows, a block per half
+    const bool preamble = (p.flags & 2u) != 0u;
+    const bool gratis = (p.flags & 1u) != 0u;
+    const float pm = kProbMax;
+    const float ninf = -__builtin_inff();
+    const int Wwin = p.min_window < T ? p.min_window : T;
+    const float mean_offset = (float)((double)(T - Wwin) / (double)C);
+    const int higher_offset = (int)mean_offset + 1;
+    const int c0 = wave * U + (lane - HL) * K;   // (negative: wave 0's halo lanes, padding)
+    const bool own = lane >= HL;
+    const bool col0_lane = wave == 0 && lane == HL;
+    const bool wave_live = wave * U + U <= C;    // every column of its own exists: stores need no masks
+    const bool stager = wave * 64 < V;
+    uint32_t laddr[K];
+    bool live[K], free_stay[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = c0 + k;
+        live[k] = c >= 0 && c < C;
+        const int g = (live[k] && c > 0) ? seg_lab[c] : -1;
+        laddr[k] = (uint32_t)(g >= 0 ? g : p.blank) * 4u;
+        free_stay[k] = gratis && g == p.blank;
+    }
+    if (tid == 0) {
+        offsets[C] = 0;
+        offsets[C + 1] = -1;
+        int sum = 0;   // the first guess (see band_fill_kernel)
+        Ob[0] = 0;
+        for (int c = 1; c < C; ++c) {
+            int b = (T - Wwin) - sum;
+            if (higher_offset < b) b = higher_offset;
+            if (c >= 2) sum += b;
+            Ob[c] = sum;
+        }
+    }
+    __syncthreads();
+    auto row_entry = [&](int tau) -> float {
+        const int f = tau < T ? tau : T - 1;
+        return seg_lpz[(int64_t)f * V + (tid < V ? tid : 0)];
+    };
+    const int nblocks = (T + R - 1) / R;
+    bool done = false;
+    for (int pass = 0; pass < kBandMaxPasses && !done; ++pass) {
+        const int W = Wwin;
+        int O[K];
+        float prev[K], best_v[K];
+        int best_t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            O[k] = live[k] ? Ob[c0 + k] : 0;
+            prev[k] = ninf;
+            best_v[k] = ninf;
+            best_t[k] = -1;
+        }
+        // emission block 0 into half 0, block 1 on its way
+        float ering[R];
+        if (stager) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) ering[r] = row_entry(r);
+            if (tid < V) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) stage[r * V + tid] = ering[r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) ering[r] = row_entry(R + r);
+        }
+        __syncthreads();
+        for (int blk = 0; blk < nblocks; ++blk) {
+            const unsigned char* half = reinterpret_cast<const unsigned char*>(stage) + (uint32_t)((blk & 1) * R * V * 4);
+            float ev[K], lbv;
+            lbv = *reinterpret_cast<const float*>(half + p.blank * 4);
+#pragma unroll
+            for (int k = 0; k < K; ++k) ev[k] = *reinterpret_cast<const float*>(half + laddr[k]);
+#pragma unroll 2   // (all 16 rows unrolled, the compiler hoists their LDS reads and spills)
+            for (int r = 0; r < R; ++r) {
+                const int tau = blk * R + r;
+                // next row's operands (the block's last row reads its own again: unused)
+                const unsigned char* nrow = half + (uint32_t)((r + 1 < R ? r + 1 : r) * V * 4);
+                const float lb_next = *reinterpret_cast<const float*>(nrow + p.blank * 4);
+                float ev_next[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) ev_next[k] = *reinterpret_cast<const float*>(nrow + laddr[k]);
+                const float left0 = dpp_wave_shr1(ninf, prev[K - 1]);   // (lane 0: nothing to its left -- the halo's growing error)
+                float nx[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float pin = k == 0 ? left0 : prev[k > 0 ? k - 1 : 0];
+                    const float b = __builtin_fmaxf(pin + ev[k], pm);
+                    float mlpz;   // max(e, -1e9): the bare instruction (fmaxf quiets its operand first: one more per cell)
+                    asm("v_max_f32 %0, %1, %2" : "=v"(mlpz) : "v"(ev[k]), "v"(pm));
+                    float m = mlpz > lbv ? mlpz : lbv;
+                    m = free_stay[k] ? 0.0f : m;   // blank_transition_cost_zero (free_stay is false without the flag)
+                    nx[k] = __builtin_fmaxf(prev[k] + m, b);
+                }
+                if (wave == 0) {   // column 0: no switch into it (table[0, 0] = 0), its own stay step
+                    const float m0 = preamble ? 0.0f : (pm > lbv ? pm : lbv);
+                    const float x0 = __builtin_fmaxf(prev[0] + m0, tau == 0 ? 0.0f : pm);
+                    nx[0] = col0_lane ? x0 : nx[0];
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool inb = live[k] && (unsigned)(tau - O[k]) < (unsigned)W;   // (padding left of column 0 stays -inf)
+                    const float x = inb ? nx[k] : ninf;
+                    prev[k] = x;
+                    const bool up = x > best_v[k];
+                    best_v[k] = up ? x : best_v[k];
+                    best_t[k] = up ? tau : best_t[k];
+                }
+                if (tau == 0 && col0_lane) {   // the package's loop over column 0 starts at row 1
+                    best_v[0] = ninf;
+                    best_t[0] = -1;
+                }
+                if (tau < T) {   // (uniform; the last block may run past the window: nothing kept)
+                    float* out = table + (int64_t)tau * C + c0;
+                    if (wave_live) {
+                        if (own) {
+                            if constexpr (K % 4 == 0) {
+#pragma unroll
+                                for (int k = 0; k < K; k += 4) *reinterpret_cast<F4U*>(out + k) = F4U{prev[k], prev[k + 1], prev[k + 2], prev[k + 3]};
+                            } else if constexpr (K % 2 == 0) {
+#pragma unroll
+                                for (int k = 0; k < K; k += 2) *reinterpret_cast<F2U*>(out + k) = F2U{prev[k], prev[k + 1]};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) out[k] = prev[k];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            if (own && live[k]) out[k] = prev[k];
+                    }
+                }
+                lbv = lb_next;
+#pragma unroll
+                for (int k = 0; k < K; ++k) ev[k] = ev_next[k];
+            }
+            // block end: the last R columns of every wave for the wave after it, the next emission block for everybody
+            if (lane >= 64 - HL) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) xch[((blk & 1) * 16 + wave) * R + (lane - (64 - HL)) * K + k] = prev[k];
+            }
+            if (stager) {
+                if (tid < V) {
+                    float* nh = stage + ((blk + 1) & 1) * R * V;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) nh[r * V + tid] = ering[r];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) ering[r] = row_entry((blk + 2) * R + r);
+            }
+            lds_barrier();
+            if (wave > 0 && lane < HL) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) prev[k] = xch[((blk & 1) * 16 + wave - 1) * R + lane * K + k];
+            }
+        }
+        // (a halo lane's maxima are its neighbour's business)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (own && live[k]) amax[c0 + k] = best_t[k];
+        __syncthreads();
+        if (tid == 0) {
+            int same = 1;
+            int sum = 0;
+            for (int c = 1; c < C; ++c) {
+                const int am = amax[c - 1];
+                int a = (am < 0 ? -1 : am - sum) - Wwin / 2;
+                if (a < 0) a = 0;
+                int b = (T - Wwin) - sum;
+                if (higher_offset < b) b = higher_offset;
+                sum += a < b ? a : b;
+                same &= Ob[c] == sum;
+                Ob[c] = sum;
+            }
+            sh_same = same;
+        }
+        __syncthreads();
+        done = sh_same != 0;
+    }
+    if (done) {
+        for (int c = tid; c < C; c += nthreads) offsets[c] = Ob[c];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            offsets[C + 1] = amax[C - 1] < 0 ? -1 : amax[C - 1] - Ob[C - 1];
+            offsets[C] = 1;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kWinThreads)
 windowed_kernel(const SegDesc* __restrict__ segs, const int32_t* __restrict__ win_list,
                 const float* __restrict__ lpz, const int32_t* __restrict__ labels,
