@@ -179,6 +179,11 @@ def test_narrowed_plans(pkg, oracle, V, monkeypatch):
     b = V - 1
     moved = [syn.make_segment(900 + s + V, T, V, U, n, blank=b, alphabet=28) for s, (T, U, n) in enumerate(shapes[:3])]
     _check(pkg, oracle, moved, _run(pkg, moved, blank=b), dict(blank=b))
+    # a narrowed batch with a window of the windowed regime in it (its own kernels, the vocabulary as it is)
+    if V in (38, 200):
+        mixed = segs[:3] + [syn.make_segment(960 + V, 900, V, 10, 14, alphabet=28)]
+        kw = dict(min_window_size=720, max_window_size=4000)
+        _check(pkg, oracle, mixed, _run(pkg, mixed, **kw), cfg_kw=kw)
     # one text of more than 31 labels in the batch: no narrowing, same answers
     if V >= 38:
         wide = segs[:2] + [syn.make_segment(990 + V, 1500, V, 12, 40)]
