@@ -47,6 +47,12 @@ struct ctcfa_engine {
     int64_t trace_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // CTCFA_CALL_TRACE
     int64_t trace_calls = 0;
     int32_t run_seq = 0;   // runs are numbered (1, 2, ...): what a fill writes into its workspace's error word when a wait gives up
+    // completion word of small host-buffer calls (BtArgs::done_word): a device counter that only grows, a pinned word the last
+    // workgroup of a call's backtrack writes the call's number to, and what the host expects of both
+    uint32_t* d_done_count = nullptr;
+    uint32_t* h_done = nullptr;        // pinned, host-coherent
+    uint32_t* d_done_word = nullptr;   // ... as the device sees it
+    uint32_t done_total = 0, done_seq = 0;
 };
 
 // Workspaces (trace words + last-column scores) a plan rotates through in the pipelined entry.  Two would do for
@@ -72,6 +78,7 @@ struct ctcfa_plan {
     SegDesc* d_segs = nullptr;
     bool scratch_owned = false;  // d_segs / d_roles / d_bits[0] / d_lastcol[0] live in the engine's scratch
     int VPbt = 0;                       // pitch of the checkpoint-mode backtrack (the vocabulary's own; VP is the FILL's: 32 for a narrowed plan)
+    uint32_t done_target = 0, done_value = 0;   // this run's backtrack writes the engine's completion word (0 / 0: no)
     bool narrow = false;                // narrowed plan (ctcfa::narrow_build): fill and backtrack stage the 32 entries each segment's text uses
     // workspaces: index 0 always; the others exist once the pipelined entry has been used
     uint32_t* d_bits[kWorkspaces] = {nullptr, nullptr, nullptr, nullptr};
@@ -492,6 +499,16 @@ int ctcfa_engine_create(ctcfa_engine** out, int device) {
         return set_err(nullptr, CTCFA_ERR_UNSUPPORTED, m);
     }
     HIP_TRY(eng, hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+    if (!std::getenv("CTCFA_NO_DONE_WORD") &&
+        hipMalloc(reinterpret_cast<void**>(&eng->d_done_count), 64) == hipSuccess &&
+        hipMemset(eng->d_done_count, 0, 64) == hipSuccess &&
+        hipHostMalloc(reinterpret_cast<void**>(&eng->h_done), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&eng->d_done_word), eng->h_done, 0) == hipSuccess) {
+        *eng->h_done = 0;
+    } else {   // (calls wait for their stream then, as before)
+        (void)hipGetLastError();
+        eng->d_done_word = nullptr;
+    }
     *out = eng;
     return CTCFA_OK;
 }
@@ -509,6 +526,8 @@ void ctcfa_engine_destroy(ctcfa_engine* eng) {
         if (sl.p) (void)hipFree(sl.p);
     if (eng->h_in) (void)hipHostFree(eng->h_in);
     if (eng->h_out) (void)hipHostFree(eng->h_out);
+    if (eng->h_done) (void)hipHostFree(eng->h_done);
+    if (eng->d_done_count) (void)hipFree(eng->d_done_count);
     if (eng->stream) (void)hipStreamDestroy(eng->stream);
     delete eng;
 }
@@ -1187,7 +1206,9 @@ int launch_backtrack(ctcfa_plan* pl, const RunArgs& a, bool want_seg, int ws, hi
                            pl->d_lastcol[ws],
                            pl->gather ? nullptr : reinterpret_cast<const int32_t*>(pl->d_lastcol[ws] + std::max<int64_t>(1, pl->total_T)),
                            pl->last_run[ws], bp, a.d_fol, a.d_char_prob, a.d_state, a.d_seg_start, a.d_seg_end,
-                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status};
+                           want_seg ? a.d_seg_score : nullptr, a.d_t_end, a.d_status,
+                           pl->done_value ? pl->eng->d_done_count : nullptr, pl->done_target,
+                           pl->done_value ? pl->eng->d_done_word : nullptr, pl->done_value};
     if (!pl->ckpt)
         hipExtLaunchKernelGGL(ctcfa::backtrack_kernel, dim3(pl->B), dim3(ctcfa::kBtThreads), pl->lds_bt, st,
                               start, (windowed || rescore) ? nullptr : stop, 0, ba);
@@ -1607,12 +1628,22 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     int32_t* d_lab = reinterpret_cast<int32_t*>(d_in + in_lab);
     int32_t* d_ub = want_seg ? reinterpret_cast<int32_t*>(d_in + in_ub) : nullptr;
     double* d_seg = want_seg ? reinterpret_cast<double*>(d_out + o_seg) : nullptr;
+    // the backtrack is this call's last kernel and writes into the pinned block: it also says when it is done
+    const bool done_word = direct_out && eng->d_done_word != nullptr;
+    if (done_word) {
+        eng->done_total += (uint32_t)pl->B;   // (one backtrack workgroup per segment)
+        eng->done_seq += 1u;
+        if (eng->done_seq == 0u) eng->done_seq = 1u;
+        pl->done_target = eng->done_total;
+        pl->done_value = eng->done_seq;
+    }
     rc = ctcfa_plan_run_device(pl, d_lpz, d_lab, d_ub, reinterpret_cast<int32_t*>(d_out + o_fol),
                                reinterpret_cast<float*>(d_out + o_cp),
                                state ? reinterpret_cast<int32_t*>(d_out + o_state) : nullptr, d_seg,
                                d_seg ? d_seg + n_utt : nullptr, d_seg ? d_seg + 2 * n_utt : nullptr,
                                reinterpret_cast<int32_t*>(d_out + o_tend), reinterpret_cast<int32_t*>(d_out + o_status), st);
     if (rc != CTCFA_OK) {
+        if (done_word) eng->d_done_word = nullptr;   // (the device counter may not have moved: no more completion words on this engine)
         cleanup();
         return rc;
     }
@@ -1620,7 +1651,21 @@ int align_impl(ctcfa_engine* eng, const ctcfa_params* params, int32_t batch, int
     unsigned char* ho = eng->h_out;
     if (!direct_out) AB_TRY(hipMemcpyAsync(ho, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     lap(4);
-    AB_TRY(hipStreamSynchronize(st));
+    bool waited = false;
+    if (done_word) {   // poll the completion word (the stream's own signal arrives ~3 us later); a second without it: the stream
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 1;; ++spins) {
+            if (__atomic_load_n(eng->h_done, __ATOMIC_ACQUIRE) == pl->done_value) {
+                waited = true;
+                break;
+            }
+            if ((spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) break;
+        }
+    }
+    if (!waited) {
+        if (done_word) eng->d_done_word = nullptr;   // (a word that did not come: this engine waits for its streams from now on)
+        AB_TRY(hipStreamSynchronize(st));
+    }
     lap(5);
     std::memcpy(frame_of_label, ho + o_fol, n_lab * 4);
     std::memcpy(char_prob, ho + o_cp, n_frm * 4);

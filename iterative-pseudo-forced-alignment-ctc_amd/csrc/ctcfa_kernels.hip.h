@@ -1930,6 +1930,13 @@ struct BtArgs {
     double* seg_score;
     int32_t* t_end_out;
     int32_t* status_out;
+    // Small host-buffer calls (stride_backtrack_kernel the last kernel of the call, results written straight into the pinned
+    // result block): the workgroup that finishes last writes `done_value` to `done_word` (pinned, host-coherent), which the
+    // host polls instead of waiting for the stream -- the runtime's completion signal costs a call ~3 us more.  NULL: off.
+    uint32_t* done_count;   // device counter, never reset: this launch's workgroups take it to done_target
+    uint32_t done_target;
+    uint32_t* done_word;
+    uint32_t done_value;
 };
 
 // NT cooperating threads (256: a workgroup of its own, 64: one wave inside a fill workgroup);
@@ -2257,9 +2264,26 @@ __device__ __forceinline__ void for_each_row(F&& f, std::integer_sequence<int, I
 // (entry 0 the blank) instead of the whole vocabulary row -- gathered from lpz, four entries of four rows per lane -- and
 // the label bytes are ring entries: the vocabulary itself may have up to 256 entries.  The ring -> vocabulary table (128
 // bytes) lies between frame_of_label and the -inf column.
+template <int P, bool NARROW>
+__device__ __forceinline__ void stride_backtrack_body(const BtArgs& a);
+
 template <int P, bool NARROW = false>   // P: LDS row pitch of a staged emission block (the vocabulary rounded up: 32 / 40 / 48 / 56 / 64)
 __global__ void __launch_bounds__(64 * kSbMaxWaves, 5)   // <= 96 VGPRs: room beside the 64-register fill tiles of the next batch
 stride_backtrack_kernel(BtArgs a) {
+    stride_backtrack_body<P, NARROW>(a);
+    if (a.done_word) {   // (uniform) every way out of the body ends here: the call's completion word
+        __threadfence_system();   // this thread's results are in the host's memory before ...
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t before = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1u == a.done_target)   // ... the last workgroup says so
+                __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <int P, bool NARROW>
+__device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_v[kSbMaxWaves];
     __shared__ int red_t[kSbMaxWaves];
