@@ -181,7 +181,8 @@ int ctcfa_plan_run_pipelined(ctcfa_plan* plan, const float* d_lpz, const int32_t
 int ctcfa_plan_flush(ctcfa_plan* plan, void* stream);
 
 /* Kernel timing with HIP events recorded on the stream the kernels run on.
- * set_timing(slots): keep the events of the last `slots` runs (0 = off, the default).
+ * set_timing(slots): keep the events of the last `slots` runs (0 = off, the default).  Called again with the same
+ * `slots` it only starts over at the first slot (the events stay: a warm-up can pay their first use).
  * set_timing_stride(k): record only every k-th run (an event record is a queue packet between
  * two kernels; k > 1 samples the run durations at a fraction of that cost).  Default 1.
  * get_timings(n, ...): durations [ms] of the last n RECORDED runs, oldest first; synchronises
