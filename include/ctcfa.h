@@ -57,8 +57,9 @@ extern "C" {
                                               T <= min_window_size; the other segments of the batch are aligned */
 #define CTCFA_ST_INTERNAL 5                /* a wave of the fill kernel gave up waiting for a progress
                                               counter (bounded spins: a bug must not hang the GPU) */
-#define CTCFA_ST_TOO_MANY_LABELS 6         /* a narrowed plan (CTCFA_FLAG_TEXTS_OF_31_LABELS) met a text that uses more than
-                                              31 vocabulary entries beside the blank; the other segments are aligned */
+#define CTCFA_ST_TOO_MANY_LABELS 6         /* a narrowed plan (CTCFA_FLAG_TEXTS_OF_31_LABELS, or created with other labels) met
+                                              a text that uses more vocabulary entries beside the blank than its ring
+                                              takes (31; 62); the other segments are aligned */
 
 /* flags (CtcSegmentationParameters.flags + the backtrack switch) */
 #define CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO 1u    /* gratis_blank; forces checkpoint mode: vocab <= 64, or (ctcfa_align_batch*) <= 63 distinct labels per segment */
@@ -274,7 +275,9 @@ int ctcfa_align_batch_spans(ctcfa_engine* eng, const ctcfa_params* params, int32
  * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes.
  * With labels given and nothing actually shared (emission_of[b] == b throughout is fine), a vocabulary of 33 .. 256 entries
  * whose segments use at most 31 labels each beside the blank gets a NARROWED plan (CTCFA_FLAG_TEXTS_OF_31_LABELS, which
- * asks for one without the labels).  Such a plan serves any later labels that keep to 31 entries per text. */
+ * asks for one without the labels); a vocabulary of 65 .. 256 entries whose texts use up to 62 a narrowed plan with a ring
+ * of 64 entries (the 64-entry kernels: checkpoint mode, blank_transition_cost_zero).  Such a plan serves any later labels
+ * that keep to 31 (62) entries per text; a text that does not gets status CTCFA_ST_TOO_MANY_LABELS. */
 int ctcfa_plan_create_shared(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* params, int32_t batch,
                              int32_t vocab, const int32_t* T, const int32_t* C, const int32_t* U,
                              const int32_t* emission_of, const int32_t* labels, int32_t force_cols_per_lane);

@@ -192,7 +192,15 @@ FillFn select_fill(int K, int VP, bool ck) {
 
 using StrideFn = void (*)(ctcfa::BtArgs);
 StrideFn select_strider(int VP, bool narrow = false) {
-    if (narrow) return VP == 32 ? ctcfa::stride_backtrack_kernel<32, true> : nullptr;
+    if (narrow) {
+        switch (VP) {
+            case 32: return ctcfa::stride_backtrack_kernel<32, true>;
+#ifndef CTCFA_DEV_VP32_ONLY
+            case 64: return ctcfa::stride_backtrack_kernel<64, true>;
+#endif
+            default: return nullptr;
+        }
+    }
     switch (VP) {
         case 32: return ctcfa::stride_backtrack_kernel<32>;
 #ifndef CTCFA_DEV_VP32_ONLY
@@ -218,7 +226,7 @@ int strider_waves(bool lone) {
 // dynamic LDS of one checkpoint-mode backtrack workgroup: rec | labels | frame_of_label | (a narrowed plan: ring entry ->
 // vocabulary entry, 128 bytes) | -inf column + NW slots | char_probs
 int lds_bytes_strider(int rec_bytes, int lab_bytes, int VP, int nw, int T, bool narrow) {
-    return rec_bytes + lab_bytes + 4 * lab_bytes + (narrow ? 128 : 0) + (nw + 1) * ctcfa::kRows * VP * 4 + T * 4;
+    return rec_bytes + lab_bytes + 4 * lab_bytes + (narrow ? VP * 4 : 0) + (nw + 1) * ctcfa::kRows * VP * 4 + T * 4;
 }
 
 // columns a tile of K columns per lane adds to the trellis (its halo lanes are copies)
@@ -729,12 +737,14 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // CTCFA_ST_TOO_MANY_LABELS), or decided here when the labels are at hand (the host-buffer entries;
     // ctcfa_plan_create_shared with labels); not with shared fills.
     bool narrowed = false;
+    int ring = 32;   // entries of the narrowed plan's ring: 32 (texts of at most 31 labels), 64 (at most 62; vocabularies above 64 entries)
     if (!gather && CTCFA_ADDTID_PRODUCER && label_width == 1 && nwatch_bound == 0 && vocab > 32 && vocab <= kMaxStagedVocab &&
         !std::getenv("CTCFA_NO_NARROW")) {
         if (params->flags & CTCFA_FLAG_TEXTS_OF_31_LABELS) {
             narrowed = true;
         } else if (labels) {
             narrowed = true;
+            int most = 0;   // labels beside the blank in the text that uses most
             int64_t o = 0;
             std::vector<int8_t> seen(vocab);
             for (int b = 0; b < batch && narrowed; o += C[b], ++b) {
@@ -747,16 +757,22 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
                     if (g < 0 || g >= vocab) narrowed = false;   // (such a segment never gets here through the Python mirror; not ours to judge)
                     else if (!seen[g]) {
                         seen[g] = 1;
-                        narrowed = ++used <= 31;
+                        narrowed = ++used <= ctcfa::narrow_max_labels(64);
                     }
                 }
+                most = std::max(most, used);
+            }
+            // (a 64-entry ring is the 64-entry kernels' pace: no gain for a vocabulary that has them anyway)
+            if (narrowed && most > ctcfa::narrow_max_labels(32)) {
+                if (vocab > 64 && !std::getenv("CTCFA_NO_RING64")) ring = 64;
+                else narrowed = false;
             }
         }
     }
     if (narrowed) {
         pl->narrow = true;
-        pl->VP = 32;
-        pl->VPbt = 32;
+        pl->VP = ring;
+        pl->VPbt = ring;
         nprod = 2;
     }
     if (gratis && vocab > 64 && !narrowed) {

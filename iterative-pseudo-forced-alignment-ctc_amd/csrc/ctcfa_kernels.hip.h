@@ -220,16 +220,21 @@ using lds_vint = volatile __attribute__((address_space(3))) int;   // counters i
 // A text with more labels than that breaks the caller's promise (CTCFA_FLAG_TEXTS_OF_31_LABELS): the backtrack reports
 // CTCFA_ST_TOO_MANY_LABELS for the segment; the fill keeps every address inside the ring (`& 31`) and its results are dropped.
 // ---------------------------------------------------------------------------------------
-constexpr int kNarrowWords = 48;
+// A ring of 64 entries (entry 63 stays free: the 64-entry producers keep lane 63 for the start column's pseudo entry) takes
+// texts of up to 62 labels over vocabularies of 65 .. 256 entries through the 64-entry kernels the same way: the table then has
+// 64 words ([16..79]).
+constexpr int kNarrowWords = 16 + 64;
 constexpr int kNarrowScratchBytes = kNarrowWords * 4 + 256;   // ... and, while the table is built, a byte per vocabulary entry behind it
+__host__ __device__ constexpr int narrow_max_labels(int ring) { return ring == 32 ? 31 : 62; }   // labels beside the blank a ring takes
 using lds_vuint = volatile __attribute__((address_space(3))) uint32_t;
 using lds_vbyte = volatile __attribute__((address_space(3))) uint8_t;
+template <int RING = 32>
 __device__ __forceinline__ void narrow_build(lds_vuint* scr, const int32_t* __restrict__ seg_lab, int C, int V, int blank, int lane) {
     // which entries the text uses: a byte each, set by plain stores (lanes that write the same byte write the same value;
     // LDS atomics on eight words serialise the 64 lanes of every instruction: ~9 us for config 3's workgroups, all at once)
     lds_vbyte* used = (lds_vbyte*)(scr + kNarrowWords);
     scr[kNarrowWords + lane] = 0u;
-    if (lane < 32) scr[16 + lane] = static_cast<uint32_t>(blank);
+    if (lane < RING) scr[16 + lane] = static_cast<uint32_t>(blank);
     // (sixteen loads in flight: one memory round trip for a text of up to 1 024 labels)
     for (int c0 = 1; c0 < C; c0 += 64 * 16) {
         int g[16];
@@ -265,7 +270,7 @@ __device__ __forceinline__ void narrow_build(lds_vuint* scr, const int32_t* __re
         const uint32_t wd = scr[g >> 5];
         if ((wd >> (g & 31)) & 1u) {
             const int r = 1 + static_cast<int>(scr[8 + (g >> 5)]) + __builtin_popcount(wd & ((1u << (g & 31)) - 1u));
-            if (r < 32) scr[16 + r] = static_cast<uint32_t>(g < V ? g : V - 1);
+            if (r < RING) scr[16 + r] = static_cast<uint32_t>(g < V ? g : V - 1);
         }
     }
 }
@@ -275,7 +280,7 @@ __device__ __forceinline__ int narrow_rank(lds_vuint* scr, int g, int blank) {
     const int r = 1 + static_cast<int>(scr[8 + ((g >> 5) & 7)]) + __builtin_popcount(word & ((1u << (g & 31)) - 1u));
     return g == blank ? 0 : r;
 }
-__device__ __forceinline__ int narrow_count(lds_vuint* scr) {   // labels beside the blank: at most 31 fit
+__device__ __forceinline__ int narrow_count(lds_vuint* scr) {   // labels beside the blank: narrow_max_labels(ring) fit
     return static_cast<int>(scr[15]) + __builtin_popcount(scr[7]);
 }
 #define CTCFA_SPIN_REPORT() do { if ((threadIdx.x & 63) == 0 && flags[20] != 0) __hip_atomic_store(fill_err, run_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
@@ -361,7 +366,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     // text uses, the tiles address the ring by ring entry
     const bool preamble = (cost_flags & 1) != 0;
     const bool gratis = (cost_flags & 2) != 0;
-    const bool narrowed = VP == 32 && CK && (cost_flags & 4) != 0;   // (narrowed plans run in checkpoint mode)
+    constexpr bool kRingPitch = VP == 32 || VP == 64;   // the pitches a narrowed plan runs at
+    const bool narrowed = kRingPitch && CK && (cost_flags & 4) != 0;   // (narrowed plans run in checkpoint mode)
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool E_ALONE = VP > 80;           // the ring holds e alone (4 B an entry), the tiles work out m: see the producers
     static_assert(!(VP > 64 && CK), "checkpoint mode exists for vocabularies of at most 64 entries");
@@ -422,11 +428,13 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
     }
     // a narrowed plan: what this wave needs of the segment's table, looked up before the barrier -- the table lies in the
     // emission ring's first slot, which no producer writes before it
-    int nar_ent = (lane >> 1) < V ? (lane >> 1) : V - 1;   // producers: the vocabulary entry behind ring entry lane >> 1 (fewer than 32 entries: the last one again)
+    // producers: the vocabulary entry behind the ring entry this lane stages -- entry lane >> 1 of the 32-entry ring (fewer
+    // than 32 entries: the last one again), entry `lane` of the 64-entry one
+    int nar_ent = VP == 64 ? (lane < V ? lane : V - 1) : ((lane >> 1) < V ? (lane >> 1) : V - 1);
     int nar_lab[K];            // tiles: the ring entries of this lane's label columns
 #pragma unroll
     for (int k = 0; k < K; ++k) nar_lab[k] = 0;
-    if (VP == 32 && CK && narrowed) {
+    if (kRingPitch && CK && narrowed) {
         lds_vuint* scr = (lds_vuint*)(smem + static_cast<uint32_t>(wave_id * kNarrowScratchBytes));
         int mine[K];   // (asked for before the scan of the text: one memory round trip for both)
 #pragma unroll
@@ -434,12 +442,12 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             const int c = my.cbase + lane * K + k - shift;
             mine[k] = (my.role != kRoleProducer && c > 0 && c < C) ? seg_lab[c] : blank;
         }
-        narrow_build(scr, seg_lab, C, V, blank, lane);
+        narrow_build<VP == 64 ? 64 : 32>(scr, seg_lab, C, V, blank, lane);
         if (my.role == kRoleProducer) {
-            nar_ent = static_cast<int>(scr[16 + (lane >> 1)]);
+            nar_ent = static_cast<int>(scr[16 + (VP == 64 ? lane : (lane >> 1))]);
         } else {
 #pragma unroll
-            for (int k = 0; k < K; ++k) nar_lab[k] = narrow_rank(scr, mine[k], blank) & 31;
+            for (int k = 0; k < K; ++k) nar_lab[k] = narrow_rank(scr, mine[k], blank) & (VP == 64 ? 63 : 31);
         }
     }
     lds_barrier();  // the only workgroup barrier: everything after it is counter-paced
@@ -788,7 +796,8 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
             // from a v_readlane, LDS offsets are immediates.  Lane VP writes the start-column pseudo
             // entry, the remaining lanes a sink.  ~6 instructions per row.
             constexpr int kPseudoLane = VP < 64 ? VP : 63;  // V < VP here, so this lane carries no entry
-            const int svl = lane < V ? lane : V - 1;             // lanes past the vocabulary re-read its last entry
+            // lanes past the vocabulary re-read its last entry; a narrowed plan's 64-entry ring: the vocabulary entry behind ring entry `lane`
+            const int svl = VP == 64 ? nar_ent : (lane < V ? lane : V - 1);
             // LDS entry a lane writes: its own, the pseudo entry VP, or (lanes past VP) the pad entry VP+1
             const uint32_t ent = static_cast<uint32_t>((lane == kPseudoLane ? VP : (lane <= VP ? lane : VP + 1)) * 8);
             // With two producers (roles->nprod == 2) each stages every other row of a block and
@@ -824,7 +833,7 @@ fill_kernel(const SegDesc* __restrict__ segs, const float* __restrict__ lpz,
                     for (int i = 0; i < NR; ++i) {
                         // (rows past the end of the segment repeat its last row -- the loads are clamped: nothing
                         // downstream reads what the tiles make of them, so they are not zeroed here)
-                        const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), blank));
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), rblank));
                         notneg |= !(e[i] <= 0.0f);
                         float2 v = make_float2(e[i], max3f(lb, e[i], kProbMax));
                         if (lane == kPseudoLane) v = make_float2(-__builtin_inff(), preamble ? 0.0f : __builtin_fmaxf(lb, kProbMax));
@@ -2262,8 +2271,8 @@ __device__ __forceinline__ void for_each_row(F&& f, std::integer_sequence<int, I
 
 // NARROW (a narrowed plan, P = 32; see narrow_build): a staged row holds the 32 vocabulary entries of the segment's ring
 // (entry 0 the blank) instead of the whole vocabulary row -- gathered from lpz, four entries of four rows per lane -- and
-// the label bytes are ring entries: the vocabulary itself may have up to 256 entries.  The ring -> vocabulary table (128
-// bytes) lies between frame_of_label and the -inf column.
+// the label bytes are ring entries: the vocabulary itself may have up to 256 entries.  The ring -> vocabulary table (4 P
+// bytes; P = 64: the 64-entry ring of texts with 32 .. 62 labels) lies between frame_of_label and the -inf column.
 template <int P, bool NARROW>
 __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a);
 
@@ -2327,7 +2336,7 @@ __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
     uint8_t* labs = smem + p.rec_bytes;
     int32_t* fol_lds = reinterpret_cast<int32_t*>(smem + p.rec_bytes + p.lab_bytes);   // frame_of_label, for the scoring
     lds_vint* nrw = (lds_vint*)(smem + p.rec_bytes + p.lab_bytes + p.fol_bytes);   // NARROW: ring entry -> vocabulary entry
-    const uint32_t neg_base = (uint32_t)(p.rec_bytes + p.lab_bytes + p.fol_bytes + (NARROW ? 128 : 0));
+    const uint32_t neg_base = (uint32_t)(p.rec_bytes + p.lab_bytes + p.fol_bytes + (NARROW ? P * 4 : 0));
     const uint32_t slot0 = neg_base + SLOT_BYTES;
     float* cps = reinterpret_cast<float*>(smem + slot0 + NW * SLOT_BYTES);   // char_probs of this segment (scoring)
 
@@ -2392,10 +2401,11 @@ __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
     bool too_many = false;
     if (NARROW) {   // every wave derives the segment's table by itself, in the slot of the first strider (nothing is staged yet)
         lds_vuint* scr = (lds_vuint*)(smem + slot0 + (uint32_t)(wave * kNarrowScratchBytes));
-        narrow_build(scr, seg_lab, C, V, p.blank, lane);
-        too_many = narrow_count(scr) > 31;   // (the same answer in every wave)
-        for (int c = tid; c < C; c += nthreads) labs[c] = (uint8_t)(c > 0 ? narrow_rank(scr, seg_lab[c], p.blank) & 31 : 0);
-        if (wave == 0 && lane < 32) nrw[lane] = (int)scr[16 + lane];
+        static_assert(!NARROW || P == 32 || P == 64, "a narrowed plan's ring has 32 or 64 entries");
+        narrow_build<P == 64 ? 64 : 32>(scr, seg_lab, C, V, p.blank, lane);
+        too_many = narrow_count(scr) > narrow_max_labels(P);   // (the same answer in every wave)
+        for (int c = tid; c < C; c += nthreads) labs[c] = (uint8_t)(c > 0 ? narrow_rank(scr, seg_lab[c], p.blank) & (P - 1) : 0);
+        if (wave == 0 && lane < P) nrw[lane] = (int)scr[16 + lane];
     }
     for (int c = tid; c < C; c += nthreads) {
         fol[c] = 0;
@@ -2467,11 +2477,12 @@ __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
         // entries, pitch 32) the row itself, its last entry repeated: the same four-by-four gather instead of a scatter of
         // 32 V contiguous floats (29 entries: 81 -> 76.5 us alone for config 3's shape, 76.5 with 32)
         const bool GATHER = NARROW || (P == 32 && V < 32);
-        int gcol[4] = {0, 0, 0, 0};    // the vocabulary entries behind staged entries 4 (lane & 7) + k
+        constexpr int LQ = P / 4;      // lanes that share a staged row (a quad of entries each)
+        int gcol[4] = {0, 0, 0, 0};    // the vocabulary entries behind staged entries 4 (lane % LQ) + k
         if (GATHER) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int q = 4 * (lane & 7) + k;
+                const int q = 4 * (lane % LQ) + k;
                 gcol[k] = NARROW ? nrw[q] : (q < V ? q : V - 1);
             }
         }
@@ -2487,10 +2498,10 @@ __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
                 stg[0].x = seg_lpz[t * V + p.blank];
                 return;
             }
-            if (GATHER) {   // quad q of lane l: staged entries 4 (l & 7) .. + 3 of row (l >> 3) + 8 q -- put()'s float4 layout at pitch 32
+            if (GATHER) {   // quad q of lane l: staged entries 4 (l % LQ) .. + 3 of row l / LQ + (64 / LQ) q -- put()'s float4 layout at pitch P
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    int t = jb * kRows + 1 + (lane >> 3) + 8 * q;
+                    int t = jb * kRows + 1 + lane / LQ + (64 / LQ) * q;
                     t = t < T ? t : T - 1;   // (rows past the end of the segment: its last row again, nobody reads them)
                     const float* __restrict__ rowp = seg_lpz + (size_t)t * (size_t)V;
                     stg[q] = make_float4(rowp[gcol[0]], rowp[gcol[1]], rowp[gcol[2]], rowp[gcol[3]]);

@@ -239,6 +239,47 @@ def test_narrowed_plan_through_the_plan_api(pkg, oracle, engine, V, how):
     plan.close()
 
 
+@pytest.mark.parametrize("V", [65, 100, 200, 256])
+def test_narrowed_plans_with_a_ring_of_64_entries(pkg, oracle, V, monkeypatch, engine):
+    """Texts of 32 .. 62 labels beside the blank over a vocabulary of more than 64 entries: the 64-entry kernels on the
+    columns each segment looks at (checkpoint mode where the plain plan has decision words only) -- same results as the
+    oracle and as the plain plan, with the flags, with the blank elsewhere; 63 labels are one too many (plain plan)."""
+    import torch
+    syn = pkg.synthetic
+    shapes = [(400, 4, 20), (700, 8, 31), (64, 1, 10), (1100, 12, 30), (1500, 14, 28)]
+    segs = [syn.make_segment(1700 + s + V, T, V, U, n, alphabet=(50, 62, 40, 45, 58)[s]) for s, (T, U, n) in enumerate(shapes)]
+    assert max(len(np.unique(g[1:])) for _, g, _ in segs) > 33
+    res = _run(pkg, segs)
+    _check(pkg, oracle, segs, res)
+    monkeypatch.setenv("CTCFA_NO_NARROW", "1")
+    plain = _run(pkg, segs)
+    monkeypatch.delenv("CTCFA_NO_NARROW")
+    for a, b in zip(res, plain):
+        for k in ("frame_of_label", "char_prob", "state", "seg_start", "seg_end", "seg_score", "t_end", "status"):
+            assert np.array_equal(a[k], b[k]), k
+    _check(pkg, oracle, segs, _run(pkg, segs, preamble_transition_cost_zero=False), dict(preamble_transition_cost_zero=0))
+    _check(pkg, oracle, segs, _run(pkg, segs, blank_transition_cost_zero=True), dict(blank_transition_cost_zero=1))
+    _check(pkg, oracle, segs, _run(pkg, segs, backtrack_from_max_t=True), dict(backtrack_from_max_t=1))
+    b = V - 1
+    moved = [syn.make_segment(1900 + s + V, T, V, U, n, blank=b, alphabet=55) for s, (T, U, n) in enumerate(shapes[:3])]
+    _check(pkg, oracle, moved, _run(pkg, moved, blank=b), dict(blank=b))
+    # through the plan API (the labels given): the 64-entry ring, pitch 64 + 2
+    T, C, U = [s[0].shape[0] for s in segs], [len(s[1]) for s in segs], [len(s[2]) - 1 for s in segs]
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    labels = np.concatenate([s[1] for s in segs]).astype(np.int32)
+    plan = engine.plan(config.to_native(), V, T, C, U, labels=labels)
+    assert plan.info["vocab_pitch"] == 66
+    plan.close()
+    if V >= 100:   # 63 labels in one text: no ring takes it
+        wide = segs[:2] + [syn.make_segment(1990 + V, 2500, V, 20, 40, alphabet=63)]
+        if len(np.unique(wide[-1][1][1:])) >= 64:
+            plan = engine.plan(config.to_native(), V, [s[0].shape[0] for s in wide], [len(s[1]) for s in wide],
+                               [len(s[2]) - 1 for s in wide], labels=np.concatenate([s[1] for s in wide]).astype(np.int32))
+            assert plan.info["vocab_pitch"] != 66
+            plan.close()
+        _check(pkg, oracle, wide, _run(pkg, wide))
+
+
 def test_narrowed_plan_reports_a_text_of_more_than_31_labels(pkg, oracle, engine):
     """CTCFA_FLAG_TEXTS_OF_31_LABELS is the caller's promise: a segment whose text breaks it gets status
     CTCFA_ST_TOO_MANY_LABELS (zeroed outputs), the other segments of the run are aligned -- 31 labels beside the blank fit,

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--cols-per-lane", type=int, default=0)
     ap.add_argument("--alphabet", type=int, default=0, help="texts use the first N non-blank entries only")
     ap.add_argument("--narrow", action="store_true", help="plans are created with CTCFA_FLAG_TEXTS_OF_31_LABELS: vocabularies above 32 entries get a narrowed plan")
+    ap.add_argument("--with-labels", action="store_true", help="plans are created with the labels of input set 0 (ctcfa_plan_create_shared): texts of up to 62 labels over more than 64 entries get the 64-entry ring")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -57,7 +58,8 @@ def main():
             os.environ.update(sets)
             try:
                 plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane,
-                                texts_of_31_labels=args.narrow)
+                                texts_of_31_labels=args.narrow,
+                                labels=host[0][1].astype(np.int32).reshape(-1) if args.with_labels else None)
             finally:
                 for k, v in old.items():
                     if v is None:
