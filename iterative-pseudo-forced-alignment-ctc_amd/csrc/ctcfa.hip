@@ -631,7 +631,7 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     const bool gratis = (params->flags & CTCFA_FLAG_BLANK_TRANSITION_COST_ZERO) != 0;
     static const char* const kGratisWide =
         "blank_transition_cost_zero needs a vocabulary of at most 64 entries, or a plan created with its labels whose texts use at "
-        "most 31 entries each beside the blank (the host-buffer and resident entries also take larger ones whose launch looks at "
+        "most 62 entries each beside the blank (the host-buffer and resident entries also take larger ones whose launch looks at "
         "no more than 63 distinct labels)";
     if (gratis && vocab > 64 &&
         !((labels || (params->flags & CTCFA_FLAG_TEXTS_OF_31_LABELS)) && label_width == 1 && vocab <= kMaxStagedVocab))   // (a narrowed plan takes it: decided below)
