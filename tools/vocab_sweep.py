@@ -14,13 +14,18 @@ syn = pkg.synthetic
 DUR = 320.4769 / 16000
 dev = torch.device("cuda:0")
 eng = pkg._native.Engine(0)
-for V in (20, 29, 32, 38, 48, 64, 76, 100, 128, 160, 192, 256, 300):  # 300: the gather kernel (V > 256)
-    base = [syn.make_segment(s, 3000, V, 22, 28) for s in range(8)]
+# texts: labels drawn from the whole vocabulary (V - 1 of them: no ring takes those above 32 / 64), from 28 entries of it (a
+# character model's window: the 32-entry ring), from 50 (the 64-entry ring above 64 entries).  Plans are created with
+# their labels, as the host-buffer entries do.
+for V, alphabet in [(V, a) for V in (20, 29, 32, 38, 48, 64, 76, 100, 128, 160, 192, 256, 300) for a in (None, 28, 50)
+                    if a is None or (a == 28 and 32 < V <= 256) or (a == 50 and 64 < V <= 256)]:
+    base = [syn.make_segment(s, 3000, V, 22, 28, alphabet=alphabet) for s in range(8)]
     segs = [base[i % 8] for i in range(512)]
     T = [s[0].shape[0] for s in segs]
     C = [len(s[1]) for s in segs]
     U = [len(s[2]) - 1 for s in segs]
-    plan = eng.plan(pkg.CtcSegmentationParameters(index_duration=DUR).to_native(), V, T, C, U)
+    plan = eng.plan(pkg.CtcSegmentationParameters(index_duration=DUR).to_native(), V, T, C, U,
+                    labels=np.concatenate([s[1] for s in segs]).astype(np.int32) if V <= 256 else None)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
     d_lpz = t(np.concatenate([s[0].reshape(-1) for s in segs]), np.float32)
     d_lab = t(np.concatenate([s[1] for s in segs]), np.int32)
@@ -41,6 +46,6 @@ for V in (20, 29, 32, 38, 48, 64, 76, 100, 128, 160, 192, 256, 300):  # 300: the
     torch.cuda.synchronize()
     fill, bt = plan.get_timings(10)
     info = plan.info
-    print(f"V={V}: K={info['cols_per_lane']} stages={info['waves_per_seg']} pitch={info['vocab_pitch']} lds={info['lds_bytes']} "
+    print(f"V={V} texts over {alphabet or V - 1} entries: K={info['cols_per_lane']} stages={info['waves_per_seg']} pitch={info['vocab_pitch']} lds={info['lds_bytes']} "
           f"fill {np.mean(fill) * 1e3:.0f} us bt {np.mean(bt) * 1e3:.0f} us", flush=True)
     plan.close()
