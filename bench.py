@@ -536,9 +536,12 @@ def main():
     eng = pkg._native.Engine(local_rank)
     # (a vocabulary above 32 entries whose texts keep to 31 of them -- --vocab 38 --alphabet 28, a character model's windows --
     # gets a narrowed plan: CTCFA_FLAG_TEXTS_OF_31_LABELS, include/ctcfa.h)
-    promise = V > 32 and all(len(np.unique(g[g != cfg.blank])) <= 32 for h in host_sets for g in h[1])   # (g[0] = -1 counts as one)
+    most = max(len(np.unique(g[g != cfg.blank])) - 1 for h in host_sets for g in h[1])   # (g[0] = -1 is not a label)
+    promise = V > 32 and most <= 31
+    # (texts of 32 .. 62 labels over more than 64 entries: the 64-entry ring, which a plan created with labels gets -- set 0's)
+    ring64 = V > 64 and 31 < most <= 62
     plan = eng.plan(cfg.to_native(), V, [T] * B, [C] * B, [U] * B, force_cols_per_lane=args.cols_per_lane,
-                    texts_of_31_labels=promise)
+                    texts_of_31_labels=promise, labels=host_sets[0][1].astype(np.int32).reshape(-1) if ring64 else None)
     info = plan.info
 
     d_in = [(torch.from_numpy(h[0].reshape(-1)).to(dev), torch.from_numpy(h[1].astype(np.int32).reshape(-1)).to(dev),
@@ -711,7 +714,7 @@ def main():
                        "segments_per_gpu": B, "frames": T, "vocab": V, "label_columns": C,
                        "input_sets": NIN, "input_bytes_resident": int(NIN * B * T * V * 4),
                        "cols_per_lane": info["cols_per_lane"], "waves_per_segment": info["waves_per_seg"],
-                       "narrowed_plan": bool(V > 32 and info["vocab_pitch"] == 34),
+                       "narrowed_plan": bool((V > 32 and info["vocab_pitch"] == 34) or (V > 64 and info["vocab_pitch"] == 66)),
                        "parallelism": f"segment-sharded x{world}", "parity": parity,
                        "gather": (f"RCCL all-gather of (start, end, score), one per {G} steps" if do_gather else None),
                        "schedule": "serial" if args.serial else "backtrack(k) overlaps fill(k+1) on a second stream"},
