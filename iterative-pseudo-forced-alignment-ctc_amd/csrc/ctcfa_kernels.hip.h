@@ -273,6 +273,14 @@ __device__ __forceinline__ void narrow_build(lds_vuint* scr, const int32_t* __re
             if (r < RING) scr[16 + r] = static_cast<uint32_t>(g < V ? g : V - 1);
         }
     }
+    // the entries the text leaves free: the vocabulary entries behind its last one, as far as there are any (nobody reads what
+    // is staged there; neighbours in the vocabulary row let the backtrack's staging load four ring entries at once)
+    const int used_n = static_cast<int>(scr[15]) + __builtin_popcount(scr[7]);
+    if (lane < RING && lane > used_n && used_n >= 1) {
+        const int last = static_cast<int>(scr[16 + (used_n < RING ? used_n : RING - 1)]);
+        const int g = last + (lane - used_n);
+        if (g < V) scr[16 + lane] = static_cast<uint32_t>(g);
+    }
 }
 // ring entry of vocabulary entry g (anything for an entry the text does not use)
 __device__ __forceinline__ int narrow_rank(lds_vuint* scr, int g, int blank) {
@@ -2486,6 +2494,7 @@ __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
                 gcol[k] = NARROW ? nrw[q] : (q < V ? q : V - 1);
             }
         }
+        const bool gquad = GATHER && gcol[1] == gcol[0] + 1 && gcol[2] == gcol[0] + 2 && gcol[3] == gcol[0] + 3;
         auto issue = [&](int jb, bool blank_only = false) {
             const int n0 = (jb * kRows + 1) * V;
             stg_n0 = n0;
@@ -2504,7 +2513,12 @@ __device__ __forceinline__ void stride_backtrack_body(const BtArgs& a) {
                     int t = jb * kRows + 1 + lane / LQ + (64 / LQ) * q;
                     t = t < T ? t : T - 1;   // (rows past the end of the segment: its last row again, nobody reads them)
                     const float* __restrict__ rowp = seg_lpz + (size_t)t * (size_t)V;
-                    stg[q] = make_float4(rowp[gcol[0]], rowp[gcol[1]], rowp[gcol[2]], rowp[gcol[3]]);
+                    if (gquad) {   // four neighbours of the vocabulary row: one load (a ring is sorted by vocabulary entry: the usual case)
+                        const F4U v = *reinterpret_cast<const F4U*>(rowp + gcol[0]);
+                        stg[q] = make_float4(v.x, v.y, v.z, v.w);
+                    } else {
+                        stg[q] = make_float4(rowp[gcol[0]], rowp[gcol[1]], rowp[gcol[2]], rowp[gcol[3]]);
+                    }
                 }
                 return;
             }
