@@ -280,6 +280,32 @@ def test_narrowed_plans_with_a_ring_of_64_entries(pkg, oracle, V, monkeypatch, e
         _check(pkg, oracle, wide, _run(pkg, wide))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_narrowed_plans(pkg, oracle, seed):
+    """Random vocabularies (33 .. 256 entries), alphabets (2 .. 62 labels: the 32-entry ring, the 64-entry ring, or none),
+    blanks, flags and ragged batches through the host-buffer entry against the oracle."""
+    rng = np.random.default_rng(77_000 + seed)
+    syn = pkg.synthetic
+    for _ in range(4):
+        V = int(rng.integers(33, 257))
+        blank = int(rng.integers(0, V))
+        alphabet = int(rng.integers(2, min(62, V - 1) + 1))
+        kw = dict(blank=blank)
+        if rng.random() < 0.3:
+            kw["preamble_transition_cost_zero"] = False
+        if rng.random() < 0.3:   # (at most 63 distinct labels: a ring, the vocabulary's own kernels, or the compact matrix take the flag)
+            kw["blank_transition_cost_zero"] = True
+        if rng.random() < 0.3:
+            kw["backtrack_from_max_t"] = True
+        segs = []
+        for s in range(int(rng.integers(1, 7))):
+            U = int(rng.integers(1, 9))
+            n = int(rng.integers(2, 33))
+            T = int(rng.integers(U * (n + 1) + 2, 3 * U * (n + 1) + 400))
+            segs.append(syn.make_segment(int(rng.integers(1 << 30)), T, V, U, n, blank=blank, alphabet=alphabet))
+        _check(pkg, oracle, segs, _run(pkg, segs, **kw), cfg_kw=kw)
+
+
 def test_narrowed_plan_reports_a_text_of_more_than_31_labels(pkg, oracle, engine):
     """CTCFA_FLAG_TEXTS_OF_31_LABELS is the caller's promise: a segment whose text breaks it gets status
     CTCFA_ST_TOO_MANY_LABELS (zeroed outputs), the other segments of the run are aligned -- 31 labels beside the blank fit,
