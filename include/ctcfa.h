@@ -71,7 +71,7 @@ extern "C" {
  * (derived from its labels on the device) and run at the pace of a 32-entry vocabulary -- config 3's shape: 0.155 ms a
  * pipelined step with 38 entries instead of 0.158, 0.165 with 200 instead of 0.467 -- and blank_transition_cost_zero is
  * taken above 64 entries.  The results are the un-narrowed plan's.  A segment that breaks the promise gets status
- * CTCFA_ST_TOO_MANY_LABELS.  Ignored for other vocabularies and for plans with shared fills; entries that get the labels on
+ * CTCFA_ST_TOO_MANY_LABELS.  Ignored for other vocabularies (shared fills narrow like any other plan); entries that get the labels on
  * the host (ctcfa_align_batch*, ctcfa_plan_create_shared with labels) check them and narrow by themselves.
  * CTCFA_NO_NARROW=1 in the environment switches narrowing off. */
 #define CTCFA_FLAG_TEXTS_OF_31_LABELS 8u
@@ -273,7 +273,7 @@ int ctcfa_align_batch_spans(ctcfa_engine* eng, const ctcfa_params* params, int32
 /* Plan for the same geometry (ctcfa_plan_run_device / _pipelined then take `d_lpz` with the shared
  * blocks once).  labels: HOST array of all segments' labels back to back, used to check the prefix
  * property; NULL = the caller vouches that members of a group with C[b] < C[longest] are prefixes.
- * With labels given and nothing actually shared (emission_of[b] == b throughout is fine), a vocabulary of 33 .. 256 entries
+ * With labels given (shared fills or none: emission_of[b] == b throughout is fine), a vocabulary of 33 .. 256 entries
  * whose segments use at most 31 labels each beside the blank gets a NARROWED plan (CTCFA_FLAG_TEXTS_OF_31_LABELS, which
  * asks for one without the labels); a vocabulary of 65 .. 256 entries whose texts use up to 62 a narrowed plan with a ring
  * of 64 entries (the 64-entry kernels: checkpoint mode, blank_transition_cost_zero).  Such a plan serves any later labels

@@ -735,10 +735,11 @@ int plan_create_impl(ctcfa_engine* eng, ctcfa_plan** out, const ctcfa_params* pa
     // workgroup).  A character model's window does (the reference's 38-token model; `bench.py --vocab 38 --alphabet 28`).
     // Asked for with CTCFA_FLAG_TEXTS_OF_31_LABELS (the caller's promise: a text that breaks it gets status
     // CTCFA_ST_TOO_MANY_LABELS), or decided here when the labels are at hand (the host-buffer entries;
-    // ctcfa_plan_create_shared with labels); not with shared fills.
+    // ctcfa_plan_create_shared with labels).  Shared fills narrow like any other plan: the leader's ring holds every label of
+    // its prefixes, and each member's backtrack derives the ring of its own text.
     bool narrowed = false;
     int ring = 32;   // entries of the narrowed plan's ring: 32 (texts of at most 31 labels), 64 (at most 62; vocabularies above 64 entries)
-    if (!gather && CTCFA_ADDTID_PRODUCER && label_width == 1 && nwatch_bound == 0 && vocab > 32 && vocab <= kMaxStagedVocab &&
+    if (!gather && CTCFA_ADDTID_PRODUCER && label_width == 1 && vocab > 32 && vocab <= kMaxStagedVocab &&
         !std::getenv("CTCFA_NO_NARROW")) {
         if (params->flags & CTCFA_FLAG_TEXTS_OF_31_LABELS) {
             narrowed = true;

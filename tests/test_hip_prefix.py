@@ -102,6 +102,26 @@ def test_leader_with_text_longer_than_audio(pkg, oracle):
     check(oracle, segs, res)
 
 
+@pytest.mark.parametrize("V,alphabet", [(38, 28), (200, 28), (100, 50)])
+def test_shared_fills_of_a_narrowed_plan(pkg, oracle, engine, V, alphabet):
+    """A narrowed plan (the 32- or the 64-entry ring) shares fills like any other: the leader's ring holds every label of
+    its prefixes; each member's backtrack derives the ring of its own text."""
+    syn = pkg.synthetic
+    segs = []
+    for g in range(6):
+        segs += prefixes(syn.make_segment(3100 + g + V, 700 + 90 * g, V, 6 + g % 3, 18, alphabet=alphabet))
+    check(oracle, segs, run(pkg, segs))
+    config = pkg.CtcSegmentationParameters(index_duration=DUR)
+    first = {}
+    emission_of = [first.setdefault(id(s[0]), b) for b, s in enumerate(segs)]
+    plan = engine.plan(config.to_native(), V, [s[0].shape[0] for s in segs], [len(s[1]) for s in segs], [len(s[2]) - 1 for s in segs],
+                       emission_of=emission_of, labels=np.concatenate([s[1] for s in segs]))
+    fills, blocks = plan.sharing()
+    assert blocks == 6 and fills == 6
+    assert plan.info["vocab_pitch"] == (34 if alphabet <= 31 else 66)
+    plan.close()
+
+
 def test_members_that_are_not_prefixes_are_filled_by_themselves(pkg, oracle, engine):
     syn = pkg.synthetic
     lpz, gt, ub = syn.make_segment(21, 500, 32, 5, 20)
